@@ -1,0 +1,186 @@
+/* pt_amd.h -- C ABI of the MI355X path-tracing library (libpt_amd.so).
+ *
+ * The reference has no plugin or FFI interface: its renderer is reached through member calls on
+ * global objects.  Each entry point below replaces one of those calls (or one global the call
+ * reads); the citation names the reference lines, relative to the reference root.
+ *
+ * Conventions: every function returns PT_OK (0) or a negative PtStatus; nothing throws and
+ * nothing is printed.  pt_last_error() returns a description of the last failure on a context.
+ * A context belongs to one host thread and one GPU.  Arrays passed in are copied; arrays passed
+ * out are written into caller memory.  Images are W*H*3 floats, row 0 = BOTTOM row, pixel
+ * (i, j) at index i + j*W (src/cs488.h:195-198).
+ */
+#ifndef PT_AMD_H
+#define PT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PtContext PtContext;
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_INVALID_ARG = -1,
+    PT_ERR_IO = -2,           /* file missing or unreadable */
+    PT_ERR_INVALID_OBJ = -3,  /* .obj parsed to zero triangles (src/cs488.h:714) */
+    PT_ERR_NOT_READY = -4,    /* call order: mesh, build, resolution, then render */
+    PT_ERR_HIP = -5,          /* a HIP runtime call failed; see pt_last_error */
+    PT_ERR_QUEUE_OVERFLOW = -6, /* forked paths outgrew the ray queues; raise PT_OPT_QUEUE_FACTOR */
+    PT_ERR_TREE_DEPTH = -7,   /* accelerator deeper than the traversal stack */
+    PT_ERR_UNSUPPORTED = -8
+} PtStatus;
+
+/* Accelerator kinds: the reference selects one at compile time with `#define KD_TREE`
+ * (src/cs488.h:1197, on by default). */
+enum { PT_ACCEL_BVH = 0, PT_ACCEL_KD = 1 };
+
+/* Material types (src/cs488.h:363-367). */
+enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_GLASS = 2 };
+
+/* The render-time fields of the reference's Material (src/cs488.h:368-389).  `name` keeps the
+ * trailing newline the reference's parser leaves on it (src/cs488.h:871). */
+typedef struct PtMaterial {
+    char name[96];
+    int32_t type;
+    float eta;
+    float Ka[3], Kd[3], Ks[3], Ke[3];
+    float Ns, opacity, roughness;
+    int32_t textured;      /* map_Kd seen (src/cs488.h:889-893) */
+    int32_t tex_width, tex_height;
+} PtMaterial;
+
+/* Options for pt_set_option / pt_get_option. */
+enum {
+    PT_OPT_SEED = 1,          /* u64 seed of the counter-based sampler (default 0xcafef00dd15ea5e5, src/cs488.h:131) */
+    PT_OPT_MAX_LEVEL = 2,     /* maxLevel (src/cs488.h:60), default 15 */
+    PT_OPT_COUNT_TESTS = 3,   /* 1: trace kernels count box and triangle tests (slower) */
+    PT_OPT_PROFILE = 4,       /* 1: bracket every kernel with HIP events on the context's stream */
+    PT_OPT_MAX_BATCH = 5,     /* most camera samples in flight in one wavefront batch */
+    PT_OPT_QUEUE_FACTOR = 6,  /* queue capacity = factor x batch (forked paths), default 4 */
+    PT_OPT_LDS_NODES = 7,     /* tree nodes staged in LDS by the trace kernels (0 = none) */
+    PT_OPT_TRAVERSAL = 8      /* 0: division-exact slab tests everywhere; 1: guarded fast slab test */
+};
+
+/* Counter indices for pt_get_counters (all cumulative since pt_reset_counters). */
+enum {
+    PT_CNT_RAYS = 0,        /* closest-hit queries (Scene::intersect calls, src/cs488.h:1750) */
+    PT_CNT_BOX_TESTS = 1,   /* AABB::intersect calls (src/cs488.h:530); needs PT_OPT_COUNT_TESTS */
+    PT_CNT_TRI_TESTS = 2,   /* raytraceTriangle calls (src/cs488.h:646); needs PT_OPT_COUNT_TESTS */
+    PT_CNT_SAMPLES = 3,     /* camera samples started */
+    PT_CNT_NAN_SAMPLES = 4, /* samples dropped by the NaN check (src/cs488.h:1841-1858) */
+    PT_CNT_HITS = 5,        /* closest-hit queries that found a triangle */
+    PT_CNT_MAX_QUEUE = 6,   /* largest ray-queue population seen */
+    PT_CNT_COUNT = 8
+};
+
+/* Timer indices for pt_get_timers (milliseconds / launches, cumulative; needs PT_OPT_PROFILE). */
+enum {
+    PT_TIMER_RAYGEN = 0, PT_TIMER_TRACE = 1, PT_TIMER_SHADE = 2, PT_TIMER_ACCUM = 3,
+    PT_TIMER_COUNT = 4
+};
+
+/* pt_create(PT_DEVICE_NONE, ...) makes a context that never touches a GPU: it can load scenes and
+ * build accelerator trees (pt_load_obj ... pt_build, pt_get_tree, pt_get_mesh) and refuses, with
+ * PT_ERR_NOT_READY, everything that renders or traces. */
+#define PT_DEVICE_NONE (-1)
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* Replaces the static construction of globalScene (src/cs488.h:1900).  `device` is a HIP device
+ * ordinal.  Fails with PT_ERR_HIP when no GPU is usable: there is no CPU fallback. */
+int pt_create(int device, PtContext** out);
+void pt_destroy(PtContext* ctx);
+const char* pt_last_error(PtContext* ctx);
+/* Use an existing HIP stream (hipStream_t as void*) for every launch instead of the context's own. */
+int pt_set_stream(PtContext* ctx, void* hip_stream);
+int pt_set_option(PtContext* ctx, int option, uint64_t value);
+int pt_get_option(PtContext* ctx, int option, uint64_t* value);
+
+/* ---- scene: TriangleMesh::load / createSingleTriangle / Image::load / Scene::addObject ------ */
+/* src/cs488.h:703-788 with ParseOBJ :917-1194 and LoadMTL :854-915.  PT_ERR_INVALID_OBJ when the
+ * file yields no triangle; the caller then falls back as src/main.cpp:9-13 does. */
+int pt_load_obj(PtContext* ctx, const char* path);
+/* src/cs488.h:814-835 */
+int pt_single_triangle(PtContext* ctx);
+/* src/cs488.h:200-218 (Radiance .hdr; rows are flipped so that row 0 is the bottom row) */
+int pt_load_env(PtContext* ctx, const char* hdr_path);
+/* The same state set from memory.  pos9/nrm9: 9 floats per triangle (3 vertices x xyz);
+ * uv6: 6 floats per triangle or NULL; matid: one index per triangle or NULL (all 0). */
+int pt_set_mesh(PtContext* ctx, int n_tris, const float* pos9, const float* nrm9, const float* uv6, const int32_t* matid);
+int pt_set_materials(PtContext* ctx, int n, const PtMaterial* mats);
+/* 8-bit RGB texels, first row first, as the reference's decoder returns them (src/cs488.h:841). */
+int pt_set_texture(PtContext* ctx, int material, const uint8_t* rgb, int width, int height);
+/* float RGB environment image, first row of the file first (flipped on store like Image::load). */
+int pt_set_env(PtContext* ctx, const float* rgb, int width, int height);
+int pt_num_triangles(PtContext* ctx);
+int pt_num_materials(PtContext* ctx);
+int pt_get_mesh(PtContext* ctx, float* pos9, float* nrm9, float* uv6, int32_t* matid);
+int pt_get_material(PtContext* ctx, int index, PtMaterial* out);
+/* decoded texture of a material (tex_width*tex_height*3 bytes) */
+int pt_get_texture(PtContext* ctx, int material, uint8_t* rgb);
+/* stored environment image (row 0 = bottom); width/height may be queried with rgb == NULL */
+int pt_get_env(PtContext* ctx, float* rgb, int* width, int* height);
+
+/* ---- accelerator: Scene::preCalc (src/cs488.h:1733-1747) ------------------------------------ */
+/* Builds the SAH BVH (src/cs488.h:1490-1667) or the SAH kd-tree (src/cs488.h:1249-1320,
+ * 1388-1400) on the CPU, flattens it and uploads mesh, materials, textures, environment and
+ * tree to the GPU. */
+int pt_build(PtContext* ctx, int accel);
+/* Host tree in the reference's node order (BVH: pre-order array index; kd: node, child pair,
+ * left subtree, right subtree).  Call with all pointers NULL to read the sizes. */
+int pt_get_tree(PtContext* ctx, int* n_nodes, int* n_refs, int* max_depth,
+                int32_t* left, int32_t* right, int32_t* first, int32_t* count, float* box6, int32_t* refs);
+
+/* ---- camera and film: the globals of src/cs488.h:48-49,74-87 ------------------------------- */
+int pt_set_camera(PtContext* ctx, const float eye[3], const float lookat[3], const float up[3], float fov_deg, float film_size);
+/* (Re)allocates and clears accumulation and frame buffers, total sample count = 0. */
+int pt_set_resolution(PtContext* ctx, int width, int height);
+/* FrameBuffer.clear + AccumulationBuffer.clear + totalSamples = 0 (src/cs488.h:2288-2290) */
+int pt_reset(PtContext* ctx);
+
+/* ---- the hot path: Scene::Pathtrace (src/cs488.h:1878-1897) --------------------------------- */
+/* One progressive frame: totalSamples += spp, spp new samples for every pixel are added to the
+ * accumulation buffer and the frame buffer is set to accumulation / totalSamples.  Asynchronous
+ * on the context's stream; pt_download / pt_synchronize wait for it. */
+int pt_render(PtContext* ctx, int spp);
+/* Sample-split form for several GPUs: of a frame that adds spp_frame samples per pixel, this
+ * context renders only sample indices [first, first + count) into its own accumulation buffer;
+ * totalSamples still advances by spp_frame.  The caller sums the accumulation buffers of all
+ * contexts (pt_accum_device_ptr) and then calls pt_resolve. */
+int pt_render_split(PtContext* ctx, int spp_frame, int first, int count);
+/* frame = accumulation / totalSamples (src/cs488.h:1860) */
+int pt_resolve(PtContext* ctx);
+int pt_total_samples(PtContext* ctx);
+int pt_synchronize(PtContext* ctx);
+/* which: 0 = accumulation buffer, 1 = frame buffer.  Synchronises. */
+int pt_download(PtContext* ctx, int which, float* dst);
+/* Device address of the accumulation buffer (W*H*3 floats), for a collective over it. */
+void* pt_accum_device_ptr(PtContext* ctx);
+/* Render into caller-owned device memory (W*H*3 floats) instead; NULL restores the internal one. */
+int pt_use_external_accum(PtContext* ctx, void* device_ptr);
+/* Image::save (src/cs488.h:219-232): clamp to [0,1], truncate to 8 bits, PNG, top row first. */
+int pt_save_png(PtContext* ctx, int which, const char* path);
+/* Raw float dump of the same image as a little-endian PFM file (bottom row first). */
+int pt_save_pfm(PtContext* ctx, int which, const char* path);
+
+/* ---- parity entry: Scene::intersect on a batch of rays (src/cs488.h:1750-1777) ------------- */
+/* rays6: n x (origin xyz, direction xyz) in host memory.  tri: index of the winning triangle in
+ * mesh order or -1; t: hit distance or FLT_MAX; bary2 (optional): the beta, gamma of
+ * src/cs488.h:661-662. */
+int pt_trace_batch(PtContext* ctx, int n, const float* rays6, int32_t* tri, float* t, float* bary2);
+/* The reference's camera rays for the current camera and resolution, pixel-centre form
+ * (src/cs488.h:1780-1794), n = W*H rays in pixel order; for tests of the camera model. */
+int pt_camera_rays(PtContext* ctx, float* rays6);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+int pt_get_counters(PtContext* ctx, uint64_t out[PT_CNT_COUNT]);
+int pt_reset_counters(PtContext* ctx);
+/* ms[i], launches[i] for i < PT_TIMER_COUNT; synchronises. */
+int pt_get_timers(PtContext* ctx, double ms[PT_TIMER_COUNT], uint64_t launches[PT_TIMER_COUNT]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_AMD_H */

@@ -26,6 +26,7 @@
 //     d.x = d.y = 0, src/cs488.h:1721-1726);
 //   * images and textures are handed in as decoded pixels by the caller; this file has no
 //     PNG or Radiance decoder (the reference uses stb_image, src/cs488.h:202,841).
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -628,8 +629,9 @@ struct Kd {
             tmin_[a].resize(n); tmax_[a].resize(n);
             for (int i = 0; i < n; i++) {  // :1221-1227
                 const Tri& T = m->tris[i];
-                tmin_[a][i] = std::fmin(std::fmin(T.p[0][a], T.p[1][a]), T.p[2][a]);
-                tmax_[a][i] = std::fmax(std::fmax(T.p[0][a], T.p[1][a]), T.p[2][a]);
+                // std::min / std::max over a list keep the FIRST of equal elements (matters for +-0)
+                tmin_[a][i] = std::min({T.p[0][a], T.p[1][a], T.p[2][a]});
+                tmax_[a][i] = std::max({T.p[0][a], T.p[1][a], T.p[2][a]});
             }
         }
         nodes.push_back(KdNode());

@@ -1,0 +1,260 @@
+// image_io.cpp -- the few image formats the path tracer touches: Radiance .hdr in (environment
+// probes, Image::load src/cs488.h:200-218), PNG in (map_Kd textures, src/cs488.h:839-846),
+// PNG out (Image::save src/cs488.h:219-232) and PFM out (raw float dumps for comparisons).
+// The reference delegates all of this to a third-party decoder; only the resulting texel values
+// matter to the renderer: RGBE texels decode to mantissa * 2^(exponent-136) (zero when the
+// exponent byte is zero), textures become 8-bit RGB with alpha dropped.
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "scene.h"
+
+namespace pt {
+
+namespace {
+
+bool read_file(const char* path, std::vector<uint8_t>& out) {
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return false;
+    fseek(fp, 0, SEEK_END);
+    long n = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    size_t got = out.empty() ? 0 : fread(out.data(), 1, out.size(), fp);
+    fclose(fp);
+    return got == out.size();
+}
+
+inline void rgbe_to_float(const uint8_t* p, float* dst) {
+    if (p[3] != 0) {
+        const float scale = ldexpf(1.0f, (int)p[3] - 136);
+        dst[0] = p[0] * scale; dst[1] = p[1] * scale; dst[2] = p[2] * scale;
+    } else {
+        dst[0] = dst[1] = dst[2] = 0.0f;
+    }
+}
+
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+
+void put_chunk(std::vector<uint8_t>& file, const char tag[4], const uint8_t* data, size_t n) {
+    put_be32(file, (uint32_t)n);
+    size_t start = file.size();
+    file.insert(file.end(), tag, tag + 4);
+    if (n) file.insert(file.end(), data, data + n);
+    uint32_t crc = (uint32_t)crc32(0L, file.data() + start, (uInt)(n + 4));
+    put_be32(file, crc);
+}
+
+int paeth(int a, int b, int c) {
+    int p = a + b - c;
+    int pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+    if (pa <= pb && pa <= pc) return a;
+    return pb <= pc ? b : c;
+}
+
+}  // namespace
+
+bool load_hdr(const char* path, HostImage& img, std::string& err) {
+    std::vector<uint8_t> buf;
+    if (!read_file(path, buf)) { err = std::string("Unable to load: ") + path; return false; }
+    size_t pos = 0;
+    auto next_line = [&](std::string& s) -> bool {
+        s.clear();
+        if (pos >= buf.size()) return false;
+        while (pos < buf.size() && buf[pos] != '\n') s.push_back((char)buf[pos++]);
+        if (pos < buf.size()) pos++;
+        return true;
+    };
+    std::string line;
+    if (!next_line(line) || (line != "#?RADIANCE" && line != "#?RGBE")) { err = "not a Radiance file"; return false; }
+    bool fmt = false;
+    while (next_line(line)) {
+        if (line.empty()) break;
+        if (line == "FORMAT=32-bit_rle_rgbe") fmt = true;
+    }
+    if (!fmt) { err = "unsupported Radiance format"; return false; }
+    int w = 0, h = 0;
+    if (!next_line(line) || sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) {
+        err = "unsupported Radiance orientation";
+        return false;
+    }
+    std::vector<uint8_t> texels((size_t)w * h * 4);
+    const uint8_t* p = buf.data() + pos;
+    const uint8_t* end = buf.data() + buf.size();
+    bool rle = w >= 8 && w < 32768 && end - p >= 4 && p[0] == 2 && p[1] == 2 && !(p[2] & 0x80);
+    if (!rle) {
+        if ((size_t)(end - p) < texels.size()) { err = "truncated Radiance file"; return false; }
+        memcpy(texels.data(), p, texels.size());
+    } else {
+        std::vector<uint8_t> scan((size_t)w * 4);
+        for (int y = 0; y < h; y++) {
+            if (end - p < 4 || p[0] != 2 || p[1] != 2 || (((int)p[2] << 8) | p[3]) != w) { err = "corrupt Radiance scanline"; return false; }
+            p += 4;
+            for (int c = 0; c < 4; c++) {
+                int x = 0;
+                while (x < w) {
+                    if (p >= end) { err = "truncated Radiance file"; return false; }
+                    int count = *p++;
+                    if (count > 128) {
+                        count -= 128;
+                        if (p >= end || x + count > w) { err = "corrupt Radiance run"; return false; }
+                        uint8_t v = *p++;
+                        for (int k = 0; k < count; k++) scan[(size_t)(x++) * 4 + c] = v;
+                    } else {
+                        if (count == 0 || end - p < count || x + count > w) { err = "corrupt Radiance run"; return false; }
+                        for (int k = 0; k < count; k++) scan[(size_t)(x++) * 4 + c] = *p++;
+                    }
+                }
+            }
+            memcpy(texels.data() + (size_t)y * w * 4, scan.data(), scan.size());
+        }
+    }
+    img.w = w; img.h = h;
+    img.rgb.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; y++) {       // file row y (top first) lands in stored row h-1-y
+        float* dst = img.rgb.data() + (size_t)(h - 1 - y) * w * 3;
+        const uint8_t* src = texels.data() + (size_t)y * w * 4;
+        for (int x = 0; x < w; x++) rgbe_to_float(src + 4 * x, dst + 3 * x);
+    }
+    return true;
+}
+
+bool load_png_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err) {
+    std::vector<uint8_t> buf;
+    if (!read_file(path, buf)) { err = std::string("cannot read ") + path; return false; }
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (buf.size() < 8 || memcmp(buf.data(), sig, 8) != 0) { err = "not a PNG file"; return false; }
+    size_t pos = 8;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, palette;
+    bool have_ihdr = false;
+    while (pos + 12 <= buf.size()) {
+        uint32_t n = be32(&buf[pos]);
+        const uint8_t* tag = &buf[pos + 4];
+        const uint8_t* data = &buf[pos + 8];
+        if (pos + 12 + (size_t)n > buf.size()) { err = "truncated PNG chunk"; return false; }
+        if (!memcmp(tag, "IHDR", 4) && n >= 13) {
+            w = (int)be32(data); h = (int)be32(data + 4);
+            depth = data[8]; ctype = data[9]; interlace = data[12];
+            have_ihdr = true;
+        } else if (!memcmp(tag, "PLTE", 4)) {
+            palette.assign(data, data + n);
+        } else if (!memcmp(tag, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + n);
+        } else if (!memcmp(tag, "IEND", 4)) {
+            break;
+        }
+        pos += 12 + (size_t)n;
+    }
+    if (!have_ihdr || w <= 0 || h <= 0) { err = "PNG without header"; return false; }
+    if (interlace) { err = "interlaced PNG is not supported"; return false; }
+    int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!channels || (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)) { err = "unsupported PNG layout"; return false; }
+    const size_t bits_pp = (size_t)channels * depth;
+    const size_t stride = ((size_t)w * bits_pp + 7) / 8;
+    const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) {
+        err = "PNG data does not inflate";
+        return false;
+    }
+    // undo the scanline filters in place
+    std::vector<uint8_t> prev(stride, 0);
+    for (int y = 0; y < h; y++) {
+        uint8_t* row = raw.data() + (size_t)y * (stride + 1);
+        const int ft = row[0];
+        uint8_t* cur = row + 1;
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int add = ft == 0 ? 0 : ft == 1 ? a : ft == 2 ? b : ft == 3 ? (a + b) / 2 : ft == 4 ? paeth(a, b, c) : -1;
+            if (add < 0) { err = "bad PNG filter"; return false; }
+            cur[i] = (uint8_t)(cur[i] + add);
+        }
+        memcpy(prev.data(), cur, stride);
+    }
+    rgb.resize((size_t)w * h * 3);
+    const int scale = depth == 1 ? 255 : depth == 2 ? 85 : depth == 4 ? 17 : 1;
+    for (int y = 0; y < h; y++) {
+        const uint8_t* cur = raw.data() + (size_t)y * (stride + 1) + 1;
+        uint8_t* dst = rgb.data() + (size_t)y * w * 3;
+        for (int x = 0; x < w; x++) {
+            auto sample = [&](int ch) -> int {  // channel value; 16-bit samples keep their high byte
+                if (depth == 16) return cur[((size_t)x * channels + ch) * 2];
+                if (depth == 8) return cur[(size_t)x * channels + ch];
+                size_t bit = (size_t)x * depth;  // sub-byte depths have one channel
+                return (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
+            };
+            if (ctype == 3) {
+                size_t idx = (size_t)sample(0) * 3;
+                for (int c = 0; c < 3; c++) dst[3 * x + c] = idx + c < palette.size() ? palette[idx + c] : 0;
+            } else if (ctype == 0 || ctype == 4) {
+                uint8_t g = (uint8_t)(depth < 8 ? sample(0) * scale : sample(0));
+                dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = g;
+            } else {
+                for (int c = 0; c < 3; c++) dst[3 * x + c] = (uint8_t)sample(c);
+            }
+        }
+    }
+    return true;
+}
+
+bool save_png_rgb8(const char* path, const uint8_t* rgb, int w, int h, std::string& err) {
+    std::vector<uint8_t> raw;
+    raw.reserve(((size_t)w * 3 + 1) * h);
+    for (int y = 0; y < h; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3);
+    }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { err = "deflate failed"; return false; }
+    std::vector<uint8_t> file;
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    file.insert(file.end(), sig, sig + 8);
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)w); put_be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    put_chunk(file, "IHDR", ihdr.data(), ihdr.size());
+    put_chunk(file, "IDAT", z.data(), zlen);
+    put_chunk(file, "IEND", nullptr, 0);
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { err = std::string("cannot write ") + path; return false; }
+    bool ok = fwrite(file.data(), 1, file.size(), fp) == file.size();
+    fclose(fp);
+    if (!ok) err = std::string("short write to ") + path;
+    return ok;
+}
+
+bool save_pfm(const char* path, const float* rgb_bottom_up, int w, int h, std::string& err) {
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { err = std::string("cannot write ") + path; return false; }
+    fprintf(fp, "PF\n%d %d\n-1.0\n", w, h);  // negative scale = little endian; PFM rows go bottom-up
+    bool ok = fwrite(rgb_bottom_up, sizeof(float), (size_t)w * h * 3, fp) == (size_t)w * h * 3;
+    fclose(fp);
+    if (!ok) err = std::string("short write to ") + path;
+    return ok;
+}
+
+void quantise_image(const float* rgb_bottom_up, int w, int h, std::vector<uint8_t>& out) {
+    out.resize((size_t)w * h * 3);
+    size_t k = 0;
+    for (int j = h - 1; j >= 0; j--) {
+        for (int i = 0; i < w; i++) {
+            for (int c = 0; c < 3; c++) {
+                float r = rgb_bottom_up[((size_t)i + (size_t)j * w) * 3 + c];
+                float clamped = r < 1.0f ? r : 1.0f;   // min(1, r) then max(.., 0): NaN ends as 0
+                clamped = clamped > 0.0f ? clamped : 0.0f;
+                out[k++] = (uint8_t)(255.0f * clamped);  // gamma 1.0 is the identity (src/cs488.h:160-164)
+            }
+        }
+    }
+}
+
+}  // namespace pt

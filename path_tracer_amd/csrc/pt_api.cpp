@@ -1,0 +1,852 @@
+// pt_api.cpp -- implementation of the C ABI declared in include/pt_amd.h: host-side scene state,
+// tree flattening, device memory, and the per-frame schedule of the wavefront kernels.
+//
+// There is no CPU rendering path in this library: every entry that produces pixels or hits
+// launches HIP kernels, and pt_create fails when no GPU can be opened.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/pt_amd.h"
+#include "device_types.h"
+#include "scene.h"
+
+using namespace pt;
+
+namespace {
+
+struct TimedSpan {
+    hipEvent_t start, stop;
+    int timer;
+};
+
+template <typename T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= count && ptr) return hipSuccess;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; count = 0; }
+        if (n == 0) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&ptr, n * sizeof(T));
+        if (e == hipSuccess) count = n;
+        return e;
+    }
+    hipError_t upload(const T* src, size_t n, hipStream_t s) {
+        hipError_t e = ensure(n > 0 ? n : 1);
+        if (e != hipSuccess || n == 0) return e;
+        return hipMemcpyAsync(ptr, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; count = 0;
+    }
+};
+
+}  // namespace
+
+struct PtContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int blocks = 2048;
+    std::string error;
+
+    // host scene
+    HostMesh mesh;
+    HostImage env;
+    HostTree tree;
+    bool built = false;
+    int accel = PT_ACCEL_BVH;
+
+    // camera and film (defaults of src/cs488.h:48-49, 74-85)
+    float eye[3] = {0.0f, 0.0f, 1.5f}, lookat[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
+    float fov = 45.0f, film = 0.032f;
+    int width = 0, height = 0;
+    int total_samples = 0;
+
+    // options
+    uint64_t seed = 0xcafef00dd15ea5e5ull;
+    int max_level = 15;
+    int count_tests = 0, profile = 0, traversal = 0;
+    size_t max_batch = (size_t)1 << 24;
+    int queue_factor = 4;
+    int lds_nodes_opt = 256;
+
+    // device scene
+    DeviceBuffer<float4> d_nodes, d_tri_pos, d_tri_nrm, d_mats;
+    DeviceBuffer<float2> d_tri_uv;
+    DeviceBuffer<int> d_refs;
+    DeviceBuffer<uint8_t> d_texels;
+    DeviceBuffer<float> d_env;
+    SceneGpu scene = {};
+
+    // film and queues
+    DeviceBuffer<float> d_accum, d_frame;
+    float* ext_accum = nullptr;
+    DeviceBuffer<float4> q_ray_o[2], q_ray_d[2], q_beta[2], d_hit, d_sample_rad;
+    DeviceBuffer<int> d_qcount;
+    DeviceBuffer<unsigned long long> d_counters;
+    size_t batch_alloc = 0;
+
+    // measurement
+    uint64_t samples_started = 0;
+    std::vector<TimedSpan> spans;
+    std::deque<hipEvent_t> event_pool;
+    double timer_ms[PT_TIMER_COUNT] = {0, 0, 0, 0};
+    uint64_t timer_launches[PT_TIMER_COUNT] = {0, 0, 0, 0};
+
+    float* accum_ptr() { return ext_accum ? ext_accum : d_accum.ptr; }
+};
+
+namespace {
+
+int fail(PtContext* c, int code, const std::string& msg) {
+    if (c) c->error = msg;
+    return code;
+}
+
+#define PT_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return fail(ctx, PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+LaunchCfg cfg_of(PtContext* c) {
+    LaunchCfg k;
+    k.stream = c->stream;
+    k.blocks = c->blocks;
+    return k;
+}
+
+hipEvent_t take_event(PtContext* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.front();
+        c->event_pool.pop_front();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ScopedTimer {
+    PtContext* c;
+    TimedSpan span;
+    bool on;
+    ScopedTimer(PtContext* ctx, int timer) : c(ctx), on(ctx->profile != 0) {
+        if (!on) return;
+        span.timer = timer;
+        span.start = take_event(c);
+        span.stop = take_event(c);
+        (void)hipEventRecord(span.start, c->stream);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        (void)hipEventRecord(span.stop, c->stream);
+        c->spans.push_back(span);
+    }
+};
+
+// folds finished event pairs into the timers; the stream must be idle
+void drain_spans(PtContext* c) {
+    for (TimedSpan& s : c->spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess) {
+            c->timer_ms[s.timer] += ms;
+            c->timer_launches[s.timer] += 1;
+        }
+        c->event_pool.push_back(s.start);
+        c->event_pool.push_back(s.stop);
+    }
+    c->spans.clear();
+}
+
+void to_public(const HostMaterial& m, PtMaterial* o) {
+    memset(o, 0, sizeof(*o));
+    snprintf(o->name, sizeof(o->name), "%s", m.name.c_str());
+    o->type = m.type; o->eta = m.eta;
+    o->Ka[0] = m.Ka.x; o->Ka[1] = m.Ka.y; o->Ka[2] = m.Ka.z;
+    o->Kd[0] = m.Kd.x; o->Kd[1] = m.Kd.y; o->Kd[2] = m.Kd.z;
+    o->Ks[0] = m.Ks.x; o->Ks[1] = m.Ks.y; o->Ks[2] = m.Ks.z;
+    o->Ke[0] = m.Ke.x; o->Ke[1] = m.Ke.y; o->Ke[2] = m.Ke.z;
+    o->Ns = m.Ns; o->opacity = m.opacity; o->roughness = m.roughness;
+    o->textured = m.textured ? 1 : 0;
+    o->tex_width = m.tex_w; o->tex_height = m.tex_h;
+}
+
+void from_public(const PtMaterial& o, HostMaterial& m) {
+    m = HostMaterial();
+    m.name = std::string(o.name, strnlen(o.name, sizeof(o.name)));
+    m.type = o.type; m.eta = o.eta;
+    m.Ka = v3(o.Ka[0], o.Ka[1], o.Ka[2]); m.Kd = v3(o.Kd[0], o.Kd[1], o.Kd[2]);
+    m.Ks = v3(o.Ks[0], o.Ks[1], o.Ks[2]); m.Ke = v3(o.Ke[0], o.Ke[1], o.Ke[2]);
+    m.Ns = o.Ns; m.opacity = o.opacity; m.roughness = o.roughness;
+    m.textured = o.textured != 0;
+}
+
+// Host tree -> device arrays (layout: device_types.h).
+int flatten_and_upload(PtContext* c) {
+    const HostTree& t = c->tree;
+    const int n = (int)t.nodes.size();
+    if (n == 0) return fail(c, PT_ERR_NOT_READY, "empty tree");
+    if (t.max_depth > TRACE_STACK) return fail(c, PT_ERR_TREE_DEPTH, "tree depth " + std::to_string(t.max_depth) + " exceeds the traversal stack");
+
+    std::vector<int> gpu_index(n, -1), order;
+    if (t.nodes[0].left >= 0) {
+        order.push_back(0);
+        gpu_index[0] = 0;
+        for (size_t head = 0; head < order.size(); head++) {
+            const HostTree::Node& nd = t.nodes[order[head]];
+            const int kids[2] = {nd.left, nd.right};
+            for (int k : kids) {
+                if (t.nodes[k].left >= 0) { gpu_index[k] = (int)order.size(); order.push_back(k); }
+            }
+        }
+    }
+    std::vector<int> refs;
+    std::vector<int> leaf_ref(n, 0);
+    auto leaf_reference = [&](int node) -> int {
+        const HostTree::Node& nd = t.nodes[node];
+        const int off = (int)refs.size();
+        refs.push_back(nd.count);
+        for (int k = 0; k < nd.count; k++) refs.push_back(t.refs[nd.first + k]);
+        return ~off;
+    };
+    std::vector<float4> nodes(order.size() * 4);
+    for (size_t g = 0; g < order.size(); g++) {
+        const HostTree::Node& nd = t.nodes[order[g]];
+        const HostTree::Node& L = t.nodes[nd.left];
+        const HostTree::Node& R = t.nodes[nd.right];
+        const int lref = L.left >= 0 ? gpu_index[nd.left] : leaf_reference(nd.left);
+        const int rref = R.left >= 0 ? gpu_index[nd.right] : leaf_reference(nd.right);
+        nodes[4 * g + 0] = make_float4(L.box[0], L.box[1], L.box[2], L.box[3]);
+        nodes[4 * g + 1] = make_float4(L.box[4], L.box[5], R.box[0], R.box[1]);
+        nodes[4 * g + 2] = make_float4(R.box[2], R.box[3], R.box[4], R.box[5]);
+        float4 q3;
+        memcpy(&q3.x, &lref, 4); memcpy(&q3.y, &rref, 4);
+        q3.z = 0.0f; q3.w = 0.0f;
+        nodes[4 * g + 3] = q3;
+    }
+    int root_ref = 0;
+    if (t.nodes[0].left < 0) root_ref = leaf_reference(0);
+
+    // triangles and materials
+    const HostMesh& m = c->mesh;
+    const int nt = m.num_tris();
+    std::vector<float4> tp(3 * (size_t)nt), tn(3 * (size_t)nt);
+    bool any_tex = false;
+    for (const HostMaterial& hm : m.materials) any_tex = any_tex || (hm.textured && !hm.tex.empty());
+    std::vector<float2> tuv(any_tex ? 3 * (size_t)nt : 0);
+    for (int i = 0; i < nt; i++) {
+        for (int k = 0; k < 3; k++) {
+            float w = 0.0f;
+            if (k == 0) { int id = m.mat[i]; memcpy(&w, &id, 4); }
+            tp[3 * i + k] = make_float4(m.pos[9 * i + 3 * k], m.pos[9 * i + 3 * k + 1], m.pos[9 * i + 3 * k + 2], w);
+            tn[3 * i + k] = make_float4(m.nrm[9 * i + 3 * k], m.nrm[9 * i + 3 * k + 1], m.nrm[9 * i + 3 * k + 2], 0.0f);
+            if (any_tex) tuv[3 * i + k] = make_float2(m.uv[6 * i + 2 * k], m.uv[6 * i + 2 * k + 1]);
+        }
+    }
+    std::vector<float4> mats(4 * m.materials.size());
+    std::vector<uint8_t> texels;
+    for (size_t i = 0; i < m.materials.size(); i++) {
+        const HostMaterial& hm = m.materials[i];
+        int type = hm.type, tw = 0, th = 0, off = 0;
+        if (hm.textured && !hm.tex.empty()) {  // a texture that failed to decode renders untextured
+            tw = hm.tex_w; th = hm.tex_h; off = (int)texels.size();
+            texels.insert(texels.end(), hm.tex.begin(), hm.tex.end());
+        }
+        float ft, fw, fh, fo;
+        memcpy(&ft, &type, 4); memcpy(&fw, &tw, 4); memcpy(&fh, &th, 4); memcpy(&fo, &off, 4);
+        mats[4 * i + 0] = make_float4(hm.Kd.x, hm.Kd.y, hm.Kd.z, ft);
+        mats[4 * i + 1] = make_float4(hm.Ks.x, hm.Ks.y, hm.Ks.z, hm.eta);
+        mats[4 * i + 2] = make_float4(hm.Ke.x, hm.Ke.y, hm.Ke.z, hm.opacity);
+        mats[4 * i + 3] = make_float4(hm.roughness, fw, fh, fo);
+    }
+    for (int id : m.mat) {
+        if (id < 0 || id >= (int)m.materials.size()) return fail(c, PT_ERR_INVALID_ARG, "triangle with a material index outside the material table");
+    }
+
+    PT_HIP(c, c->d_nodes.upload(nodes.data(), nodes.size(), c->stream));
+    PT_HIP(c, c->d_refs.upload(refs.data(), refs.size(), c->stream));
+    PT_HIP(c, c->d_tri_pos.upload(tp.data(), tp.size(), c->stream));
+    PT_HIP(c, c->d_tri_nrm.upload(tn.data(), tn.size(), c->stream));
+    PT_HIP(c, c->d_tri_uv.upload(tuv.data(), tuv.size(), c->stream));
+    PT_HIP(c, c->d_mats.upload(mats.data(), mats.size(), c->stream));
+    PT_HIP(c, c->d_texels.upload(texels.data(), texels.size(), c->stream));
+    PT_HIP(c, c->d_env.upload(c->env.rgb.data(), c->env.rgb.size(), c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));  // the staging vectors die with this scope
+
+    SceneGpu& s = c->scene;
+    s.nodes = c->d_nodes.ptr; s.refs = c->d_refs.ptr;
+    s.tri_pos = c->d_tri_pos.ptr; s.tri_nrm = c->d_tri_nrm.ptr; s.tri_uv = c->d_tri_uv.ptr;
+    s.mats = c->d_mats.ptr; s.texels = c->d_texels.ptr; s.env = c->d_env.ptr;
+    s.env_w = c->env.w; s.env_h = c->env.h;
+    for (int k = 0; k < 3; k++) { s.root_lo[k] = t.nodes[0].box[k]; s.root_hi[k] = t.nodes[0].box[3 + k]; }
+    s.root_ref = root_ref;
+    s.n_nodes = (int)order.size();
+    s.lds_nodes = c->lds_nodes_opt < s.n_nodes ? c->lds_nodes_opt : s.n_nodes;
+    s.n_tris = nt;
+    return PT_OK;
+}
+
+void camera_of(PtContext* c, CameraGpu& cam) {
+    // Scene::generateRay (src/cs488.h:1825-1836) with the view direction of :2284 and the film
+    // distance of :79
+    const vec3 eye = v3(c->eye[0], c->eye[1], c->eye[2]);
+    const vec3 view = normalize(v3(c->lookat[0], c->lookat[1], c->lookat[2]) - eye);
+    const vec3 upn = normalize(v3(c->up[0], c->up[1], c->up[2]));
+    const vec3 w = normalize(-view);
+    const vec3 u = normalize(cross(upn, w));
+    const vec3 v = cross(w, u);
+    const float aspect = float(c->width / float(c->height));
+    const float deg_to_rad = PT_PI / 180.0f;
+    cam.eye[0] = eye.x; cam.eye[1] = eye.y; cam.eye[2] = eye.z;
+    cam.u[0] = u.x; cam.u[1] = u.y; cam.u[2] = u.z;
+    cam.v[0] = v.x; cam.v[1] = v.y; cam.v[2] = v.z;
+    cam.w[0] = w.x; cam.w[1] = w.y; cam.w[2] = w.z;
+    cam.aspect_film = aspect * c->film;
+    cam.film = c->film;
+    cam.dist = c->film / (2.0f * tanf(c->fov * deg_to_rad * 0.5f));
+    cam.width = c->width; cam.height = c->height;
+}
+
+int ensure_queues(PtContext* c, size_t batch) {
+    if (batch <= c->batch_alloc) return PT_OK;
+    const size_t cap = batch * (size_t)c->queue_factor;
+    for (int k = 0; k < 2; k++) {
+        PT_HIP(c, c->q_ray_o[k].ensure(cap));
+        PT_HIP(c, c->q_ray_d[k].ensure(cap));
+        PT_HIP(c, c->q_beta[k].ensure(cap));
+    }
+    PT_HIP(c, c->d_hit.ensure(cap));
+    PT_HIP(c, c->d_sample_rad.ensure(batch));
+    c->batch_alloc = batch;
+    return PT_OK;
+}
+
+int check_device_flags(PtContext* c) {
+    unsigned long long ov = 0;
+    PT_HIP(c, hipMemcpy(&ov, c->d_counters.ptr + DC_OVERFLOW, sizeof(ov), hipMemcpyDeviceToHost));
+    if (ov) {
+        unsigned long long zero = 0;
+        (void)hipMemcpy(c->d_counters.ptr + DC_OVERFLOW, &zero, sizeof(zero), hipMemcpyHostToDevice);
+        return fail(c, PT_ERR_QUEUE_OVERFLOW, "ray queue overflow: paths were dropped; raise PT_OPT_QUEUE_FACTOR");
+    }
+    return PT_OK;
+}
+
+// One wavefront batch: camera rays, then trace + shade per bounce level, then accumulate.
+int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int sample0, int chunk) {
+    BatchGpu b;
+    b.pixel0 = pixel0; b.n_pixels = n_pixels; b.chunk = chunk; b.sample0 = sample0;
+    b.seed = c->seed;
+    b.n_slots = n_pixels * chunk;
+    b.cap = (int)(c->batch_alloc * (size_t)c->queue_factor);
+    const LaunchCfg cfg = cfg_of(c);
+    const int levels = c->max_level + 2;  // levels 0 .. maxLevel+1; the last one only resolves misses
+    PT_HIP(c, c->d_qcount.ensure((size_t)levels + 1));
+    PT_HIP(c, hipMemsetAsync(c->d_qcount.ptr, 0, sizeof(int) * ((size_t)levels + 1), c->stream));
+    QueueSet q[2];
+    for (int k = 0; k < 2; k++) { q[k].ray_o = c->q_ray_o[k].ptr; q[k].ray_d = c->q_ray_d[k].ptr; q[k].beta = c->q_beta[k].ptr; }
+    {
+        ScopedTimer tm(c, PT_TIMER_RAYGEN);
+        PT_HIP(c, launch_raygen(cfg, cam, b, q[0], c->d_sample_rad.ptr, c->d_qcount.ptr));
+    }
+    for (int level = 0; level < levels; level++) {
+        const QueueSet& in = q[level & 1];
+        const QueueSet& out = q[(level + 1) & 1];
+        {
+            ScopedTimer tm(c, PT_TIMER_TRACE);
+            PT_HIP(c, launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, in.ray_o, in.ray_d,
+                                   c->d_hit.ptr, c->d_qcount.ptr + level, 0, c->d_counters.ptr));
+        }
+        {
+            ScopedTimer tm(c, PT_TIMER_SHADE);
+            PT_HIP(c, launch_shade(cfg, c->scene, b, level, c->max_level, in, c->d_hit.ptr, out, c->d_sample_rad.ptr,
+                                   c->d_qcount.ptr + level, c->d_qcount.ptr + level + 1, c->d_counters.ptr));
+        }
+    }
+    {
+        ScopedTimer tm(c, PT_TIMER_ACCUM);
+        PT_HIP(c, launch_accumulate(cfg, b, c->d_sample_rad.ptr, c->accum_ptr(), c->d_counters.ptr));
+    }
+    c->samples_started += (uint64_t)b.n_slots;
+    return PT_OK;
+}
+
+int render_range(PtContext* c, int spp_frame, int first, int count) {
+    if (!c->built) return fail(c, PT_ERR_NOT_READY, "pt_build has not been called");
+    if (c->width <= 0 || c->height <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
+    if (spp_frame <= 0 || first < 0 || count < 0 || first + count > spp_frame) return fail(c, PT_ERR_INVALID_ARG, "bad sample range");
+    PT_HIP(c, hipSetDevice(c->device));
+    const int base = c->total_samples;  // global index of this frame's first sample
+    c->total_samples += spp_frame;      // src/cs488.h:1882
+    const size_t n_pixels = (size_t)c->width * c->height;
+    if (count > 0) {
+        CameraGpu cam;
+        camera_of(c, cam);
+        // batches: whole image x sample chunk when a chunk of at least one sample fits, else pixel ranges x 1
+        size_t chunk = c->max_batch / n_pixels;
+        size_t pix_per_batch = n_pixels;
+        if (chunk == 0) { chunk = 1; pix_per_batch = c->max_batch; }
+        if (chunk > (size_t)count) chunk = (size_t)count;
+        int rc = ensure_queues(c, pix_per_batch * chunk);
+        if (rc != PT_OK) return rc;
+        for (size_t p0 = 0; p0 < n_pixels; p0 += pix_per_batch) {
+            const size_t np = p0 + pix_per_batch <= n_pixels ? pix_per_batch : n_pixels - p0;
+            for (int s = 0; s < count; s += (int)chunk) {
+                const int ch = s + (int)chunk <= count ? (int)chunk : count - s;
+                rc = run_batch(c, cam, (int)p0, (int)np, base + first + s, ch);
+                if (rc != PT_OK) return rc;
+            }
+        }
+    }
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_create(int device, PtContext** out) {
+    if (!out) return PT_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (device == PT_DEVICE_NONE) {  // scene and tree construction only; nothing here can render
+        PtContext* h = new PtContext();
+        h->device = PT_DEVICE_NONE;
+        *out = h;
+        return PT_OK;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PT_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return PT_ERR_HIP;
+    PtContext* c = new PtContext();
+    c->device = device;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PT_ERR_HIP; }
+    c->own_stream = true;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->blocks = prop.multiProcessorCount * 8;
+    if (c->d_counters.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_counters.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess) {
+        pt_destroy(c);
+        return PT_ERR_HIP;
+    }
+    *out = c;
+    return PT_OK;
+}
+
+void pt_destroy(PtContext* c) {
+    if (!c) return;
+    if (c->device == PT_DEVICE_NONE) { delete c; return; }
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drain_spans(c);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    c->d_nodes.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
+    c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
+    for (int k = 0; k < 2; k++) { c->q_ray_o[k].release(); c->q_ray_d[k].release(); c->q_beta[k].release(); }
+    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_counters.release();
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* pt_last_error(PtContext* c) { return c ? c->error.c_str() : "null context"; }
+
+int pt_set_stream(PtContext* c, void* hip_stream) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return PT_OK;
+}
+
+int pt_set_option(PtContext* c, int option, uint64_t value) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    switch (option) {
+        case PT_OPT_SEED: c->seed = value; break;
+        case PT_OPT_MAX_LEVEL:
+            if (value > 62) return fail(c, PT_ERR_INVALID_ARG, "max level above 62");
+            c->max_level = (int)value; break;
+        case PT_OPT_COUNT_TESTS: c->count_tests = value != 0; break;
+        case PT_OPT_PROFILE: c->profile = value != 0; break;
+        case PT_OPT_MAX_BATCH:
+            if (value == 0 || value > ((uint64_t)1 << 28)) return fail(c, PT_ERR_INVALID_ARG, "batch size out of range");
+            c->max_batch = (size_t)value; c->batch_alloc = 0; break;
+        case PT_OPT_QUEUE_FACTOR:
+            if (value < 2 || value > 64) return fail(c, PT_ERR_INVALID_ARG, "queue factor out of range");
+            c->queue_factor = (int)value; c->batch_alloc = 0; break;
+        case PT_OPT_LDS_NODES:
+            if (value > 2048) return fail(c, PT_ERR_INVALID_ARG, "at most 2048 nodes fit the LDS stage");
+            c->lds_nodes_opt = (int)value;
+            c->scene.lds_nodes = c->lds_nodes_opt < c->scene.n_nodes ? c->lds_nodes_opt : c->scene.n_nodes;
+            break;
+        case PT_OPT_TRAVERSAL: c->traversal = (int)value; break;
+        default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
+    }
+    return PT_OK;
+}
+
+int pt_get_option(PtContext* c, int option, uint64_t* value) {
+    if (!c || !value) return PT_ERR_INVALID_ARG;
+    switch (option) {
+        case PT_OPT_SEED: *value = c->seed; break;
+        case PT_OPT_MAX_LEVEL: *value = (uint64_t)c->max_level; break;
+        case PT_OPT_COUNT_TESTS: *value = (uint64_t)c->count_tests; break;
+        case PT_OPT_PROFILE: *value = (uint64_t)c->profile; break;
+        case PT_OPT_MAX_BATCH: *value = (uint64_t)c->max_batch; break;
+        case PT_OPT_QUEUE_FACTOR: *value = (uint64_t)c->queue_factor; break;
+        case PT_OPT_LDS_NODES: *value = (uint64_t)c->lds_nodes_opt; break;
+        case PT_OPT_TRAVERSAL: *value = (uint64_t)c->traversal; break;
+        default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
+    }
+    return PT_OK;
+}
+
+// ---- scene ----
+int pt_load_obj(PtContext* c, const char* path) {
+    if (!c || !path) return PT_ERR_INVALID_ARG;
+    c->built = false;
+    std::string err;
+    if (!load_obj(path, c->mesh, err)) {
+        FILE* probe = fopen(path, "r");
+        if (!probe) return fail(c, PT_ERR_IO, err);
+        fclose(probe);
+        return fail(c, PT_ERR_INVALID_OBJ, err);
+    }
+    return PT_OK;
+}
+
+int pt_single_triangle(PtContext* c) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    c->built = false;
+    make_single_triangle(c->mesh);
+    return PT_OK;
+}
+
+int pt_load_env(PtContext* c, const char* path) {
+    if (!c || !path) return PT_ERR_INVALID_ARG;
+    std::string err;
+    HostImage img;
+    if (!load_hdr(path, img, err)) return fail(c, PT_ERR_IO, err);
+    c->env = img;
+    c->built = false;
+    return PT_OK;
+}
+
+int pt_set_mesh(PtContext* c, int n, const float* pos9, const float* nrm9, const float* uv6, const int32_t* matid) {
+    if (!c || n <= 0 || !pos9 || !nrm9) return fail(c, PT_ERR_INVALID_ARG, "pt_set_mesh: bad arguments");
+    c->built = false;
+    c->mesh.pos.assign(pos9, pos9 + 9 * (size_t)n);
+    c->mesh.nrm.assign(nrm9, nrm9 + 9 * (size_t)n);
+    if (uv6) c->mesh.uv.assign(uv6, uv6 + 6 * (size_t)n); else c->mesh.uv.assign(6 * (size_t)n, 0.0f);
+    if (matid) c->mesh.mat.assign(matid, matid + n); else c->mesh.mat.assign(n, 0);
+    if (c->mesh.materials.empty()) c->mesh.materials.resize(1);
+    return PT_OK;
+}
+
+int pt_set_materials(PtContext* c, int n, const PtMaterial* mats) {
+    if (!c || n <= 0 || !mats) return fail(c, PT_ERR_INVALID_ARG, "pt_set_materials: bad arguments");
+    c->built = false;
+    c->mesh.materials.resize(n);
+    for (int i = 0; i < n; i++) from_public(mats[i], c->mesh.materials[i]);
+    return PT_OK;
+}
+
+int pt_set_texture(PtContext* c, int material, const uint8_t* rgb, int w, int h) {
+    if (!c || !rgb || w <= 0 || h <= 0 || material < 0 || material >= (int)c->mesh.materials.size())
+        return fail(c, PT_ERR_INVALID_ARG, "pt_set_texture: bad arguments");
+    HostMaterial& m = c->mesh.materials[material];
+    m.tex.assign(rgb, rgb + (size_t)w * h * 3);
+    m.tex_w = w; m.tex_h = h;
+    m.textured = true;
+    c->built = false;
+    return PT_OK;
+}
+
+int pt_set_env(PtContext* c, const float* rgb, int w, int h) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    c->built = false;
+    if (!rgb || w <= 0 || h <= 0) { c->env = HostImage(); return PT_OK; }
+    c->env.w = w; c->env.h = h;
+    c->env.rgb.resize((size_t)w * h * 3);
+    for (int y = 0; y < h; y++) memcpy(&c->env.rgb[(size_t)(h - 1 - y) * w * 3], rgb + (size_t)y * w * 3, sizeof(float) * 3 * (size_t)w);
+    return PT_OK;
+}
+
+int pt_num_triangles(PtContext* c) { return c ? c->mesh.num_tris() : PT_ERR_INVALID_ARG; }
+int pt_num_materials(PtContext* c) { return c ? (int)c->mesh.materials.size() : PT_ERR_INVALID_ARG; }
+
+int pt_get_mesh(PtContext* c, float* pos9, float* nrm9, float* uv6, int32_t* matid) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    const size_t n = (size_t)c->mesh.num_tris();
+    if (pos9) memcpy(pos9, c->mesh.pos.data(), sizeof(float) * 9 * n);
+    if (nrm9) memcpy(nrm9, c->mesh.nrm.data(), sizeof(float) * 9 * n);
+    if (uv6) memcpy(uv6, c->mesh.uv.data(), sizeof(float) * 6 * n);
+    if (matid) memcpy(matid, c->mesh.mat.data(), sizeof(int32_t) * n);
+    return PT_OK;
+}
+
+int pt_get_material(PtContext* c, int index, PtMaterial* out) {
+    if (!c || !out || index < 0 || index >= (int)c->mesh.materials.size()) return fail(c, PT_ERR_INVALID_ARG, "pt_get_material: bad index");
+    to_public(c->mesh.materials[index], out);
+    return PT_OK;
+}
+
+int pt_get_texture(PtContext* c, int material, uint8_t* rgb) {
+    if (!c || !rgb || material < 0 || material >= (int)c->mesh.materials.size()) return fail(c, PT_ERR_INVALID_ARG, "pt_get_texture: bad index");
+    const HostMaterial& m = c->mesh.materials[material];
+    if (m.tex.empty()) return fail(c, PT_ERR_NOT_READY, "material has no decoded texture");
+    memcpy(rgb, m.tex.data(), m.tex.size());
+    return PT_OK;
+}
+
+int pt_get_env(PtContext* c, float* rgb, int* w, int* h) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (w) *w = c->env.w;
+    if (h) *h = c->env.h;
+    if (rgb && !c->env.rgb.empty()) memcpy(rgb, c->env.rgb.data(), sizeof(float) * c->env.rgb.size());
+    return PT_OK;
+}
+
+// ---- accelerator ----
+int pt_build(PtContext* c, int accel) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (accel != PT_ACCEL_BVH && accel != PT_ACCEL_KD) return fail(c, PT_ERR_INVALID_ARG, "unknown accelerator kind");
+    if (c->mesh.num_tris() == 0) return fail(c, PT_ERR_NOT_READY, "no mesh loaded");
+    c->accel = accel;
+    if (accel == PT_ACCEL_KD) build_kd(c->mesh, c->tree); else build_bvh(c->mesh, c->tree);
+    if (c->device == PT_DEVICE_NONE) return PT_OK;  // tree available through pt_get_tree; not renderable
+    PT_HIP(c, hipSetDevice(c->device));
+    int rc = flatten_and_upload(c);
+    if (rc != PT_OK) return rc;
+    c->built = true;
+    return PT_OK;
+}
+
+int pt_get_tree(PtContext* c, int* n_nodes, int* n_refs, int* max_depth, int32_t* left, int32_t* right, int32_t* first,
+                int32_t* count, float* box6, int32_t* refs) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    const HostTree& t = c->tree;
+    if (n_nodes) *n_nodes = (int)t.nodes.size();
+    if (n_refs) *n_refs = (int)t.refs.size();
+    if (max_depth) *max_depth = t.max_depth;
+    for (size_t i = 0; i < t.nodes.size(); i++) {
+        if (left) left[i] = t.nodes[i].left;
+        if (right) right[i] = t.nodes[i].right;
+        if (first) first[i] = t.nodes[i].first;
+        if (count) count[i] = t.nodes[i].count;
+        if (box6) memcpy(box6 + 6 * i, t.nodes[i].box, sizeof(float) * 6);
+    }
+    if (refs && !t.refs.empty()) memcpy(refs, t.refs.data(), sizeof(int32_t) * t.refs.size());
+    return PT_OK;
+}
+
+// ---- camera and film ----
+int pt_set_camera(PtContext* c, const float eye[3], const float lookat[3], const float up[3], float fov_deg, float film_size) {
+    if (!c || !eye || !lookat || !up) return PT_ERR_INVALID_ARG;
+    for (int k = 0; k < 3; k++) { c->eye[k] = eye[k]; c->lookat[k] = lookat[k]; c->up[k] = up[k]; }
+    c->fov = fov_deg; c->film = film_size;
+    return PT_OK;
+}
+
+int pt_set_resolution(PtContext* c, int width, int height) {
+    if (!c || width <= 0 || height <= 0) return fail(c, PT_ERR_INVALID_ARG, "bad resolution");
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipSetDevice(c->device));
+    c->width = width; c->height = height;
+    const size_t n = (size_t)width * height * 3;
+    PT_HIP(c, c->d_accum.ensure(n));
+    PT_HIP(c, c->d_frame.ensure(n));
+    return pt_reset(c);
+}
+
+int pt_reset(PtContext* c) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
+    const size_t n = (size_t)c->width * c->height * 3;
+    PT_HIP(c, launch_clear(cfg_of(c), c->accum_ptr(), n));
+    PT_HIP(c, launch_clear(cfg_of(c), c->d_frame.ptr, n));
+    c->total_samples = 0;
+    return PT_OK;
+}
+
+// ---- hot path ----
+int pt_render(PtContext* c, int spp) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    int rc = render_range(c, spp, 0, spp);
+    if (rc != PT_OK) return rc;
+    return pt_resolve(c);
+}
+
+int pt_render_split(PtContext* c, int spp_frame, int first, int count) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    return render_range(c, spp_frame, first, count);
+}
+
+int pt_resolve(PtContext* c) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
+    ScopedTimer tm(c, PT_TIMER_ACCUM);
+    PT_HIP(c, launch_resolve(cfg_of(c), c->accum_ptr(), c->d_frame.ptr, c->width * c->height, c->total_samples));
+    return PT_OK;
+}
+
+int pt_total_samples(PtContext* c) { return c ? c->total_samples : PT_ERR_INVALID_ARG; }
+
+int pt_synchronize(PtContext* c) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    return check_device_flags(c);
+}
+
+int pt_download(PtContext* c, int which, float* dst) {
+    if (!c || !dst) return PT_ERR_INVALID_ARG;
+    if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
+    int rc = pt_synchronize(c);
+    if (rc != PT_OK) return rc;
+    const size_t n = (size_t)c->width * c->height * 3;
+    PT_HIP(c, hipMemcpy(dst, which == 0 ? c->accum_ptr() : c->d_frame.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+void* pt_accum_device_ptr(PtContext* c) { return c ? (void*)c->accum_ptr() : nullptr; }
+
+int pt_use_external_accum(PtContext* c, void* device_ptr) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    c->ext_accum = (float*)device_ptr;
+    return PT_OK;
+}
+
+static int save_image(PtContext* c, int which, const char* path, bool png) {
+    if (!c || !path) return PT_ERR_INVALID_ARG;
+    std::vector<float> img((size_t)c->width * c->height * 3);
+    int rc = pt_download(c, which, img.data());
+    if (rc != PT_OK) return rc;
+    std::string err;
+    if (png) {
+        std::vector<uint8_t> q;
+        quantise_image(img.data(), c->width, c->height, q);
+        if (!save_png_rgb8(path, q.data(), c->width, c->height, err)) return fail(c, PT_ERR_IO, err);
+    } else if (!save_pfm(path, img.data(), c->width, c->height, err)) {
+        return fail(c, PT_ERR_IO, err);
+    }
+    return PT_OK;
+}
+
+int pt_save_png(PtContext* c, int which, const char* path) { return save_image(c, which, path, true); }
+int pt_save_pfm(PtContext* c, int which, const char* path) { return save_image(c, which, path, false); }
+
+// ---- parity entry ----
+int pt_trace_batch(PtContext* c, int n, const float* rays6, int32_t* tri, float* t, float* bary2) {
+    if (!c || n < 0 || (n > 0 && (!rays6 || !tri || !t))) return fail(c, PT_ERR_INVALID_ARG, "pt_trace_batch: bad arguments");
+    if (!c->built) return fail(c, PT_ERR_NOT_READY, "pt_build has not been called");
+    if (n == 0) return PT_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    DeviceBuffer<float> d_rays, d_t, d_bary;
+    DeviceBuffer<int> d_tri;
+    DeviceBuffer<float4> d_o, d_d, d_h;
+    int rc = PT_OK;
+    auto body = [&]() -> int {
+        PT_HIP(c, d_rays.upload(rays6, 6 * (size_t)n, c->stream));
+        PT_HIP(c, d_o.ensure(n)); PT_HIP(c, d_d.ensure(n)); PT_HIP(c, d_h.ensure(n));
+        PT_HIP(c, d_tri.ensure(n)); PT_HIP(c, d_t.ensure(n)); PT_HIP(c, d_bary.ensure(2 * (size_t)n));
+        const LaunchCfg cfg = cfg_of(c);
+        PT_HIP(c, launch_pack_rays(cfg, d_rays.ptr, n, d_o.ptr, d_d.ptr));
+        {
+            ScopedTimer tm(c, PT_TIMER_TRACE);
+            PT_HIP(c, launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, d_o.ptr, d_d.ptr, d_h.ptr,
+                                   nullptr, n, c->d_counters.ptr));
+        }
+        PT_HIP(c, launch_unpack_hits(cfg, d_h.ptr, n, d_tri.ptr, d_t.ptr, d_bary.ptr));
+        PT_HIP(c, hipMemcpyAsync(tri, d_tri.ptr, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        PT_HIP(c, hipMemcpyAsync(t, d_t.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        if (bary2) PT_HIP(c, hipMemcpyAsync(bary2, d_bary.ptr, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+        return PT_OK;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(c->stream);
+    d_rays.release(); d_t.release(); d_bary.release(); d_tri.release(); d_o.release(); d_d.release(); d_h.release();
+    return rc;
+}
+
+int pt_camera_rays(PtContext* c, float* rays6) {
+    if (!c || !rays6) return PT_ERR_INVALID_ARG;
+    if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
+    CameraGpu cam;
+    camera_of(c, cam);
+    const vec3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
+    const vec3 u = v3(cam.u[0], cam.u[1], cam.u[2]), v = v3(cam.v[0], cam.v[1], cam.v[2]), w = v3(cam.w[0], cam.w[1], cam.w[2]);
+    size_t k = 0;
+    for (int y = 0; y < cam.height; y++) {
+        for (int x = 0; x < cam.width; x++) {
+            const float U = (x + 0.5f) / float(cam.width) - 0.5f;   // src/cs488.h:1788-1789
+            const float V = (y + 0.5f) / float(cam.height) - 0.5f;
+            const vec3 pix = eye + float(cam.aspect_film * U) * u + float(cam.film * V) * v - cam.dist * w;
+            const vec3 d = normalize(pix - eye);
+            rays6[k++] = eye.x; rays6[k++] = eye.y; rays6[k++] = eye.z;
+            rays6[k++] = d.x; rays6[k++] = d.y; rays6[k++] = d.z;
+        }
+    }
+    return PT_OK;
+}
+
+// ---- measurement ----
+int pt_get_counters(PtContext* c, uint64_t out[PT_CNT_COUNT]) {
+    if (!c || !out) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    int rc = pt_synchronize(c);
+    if (rc != PT_OK) return rc;
+    unsigned long long d[DC_COUNT];
+    PT_HIP(c, hipMemcpy(d, c->d_counters.ptr, sizeof(d), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(uint64_t) * PT_CNT_COUNT);
+    out[PT_CNT_RAYS] = d[DC_RAYS];
+    out[PT_CNT_BOX_TESTS] = d[DC_BOX];
+    out[PT_CNT_TRI_TESTS] = d[DC_TRI];
+    out[PT_CNT_SAMPLES] = c->samples_started;
+    out[PT_CNT_NAN_SAMPLES] = d[DC_NAN];
+    out[PT_CNT_HITS] = d[DC_HITS];
+    out[PT_CNT_MAX_QUEUE] = d[DC_MAXQ];
+    return PT_OK;
+}
+
+int pt_reset_counters(PtContext* c) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    PT_HIP(c, hipMemset(c->d_counters.ptr, 0, DC_COUNT * sizeof(unsigned long long)));
+    c->samples_started = 0;
+    for (int i = 0; i < PT_TIMER_COUNT; i++) { c->timer_ms[i] = 0; c->timer_launches[i] = 0; }
+    return PT_OK;
+}
+
+int pt_get_timers(PtContext* c, double ms[PT_TIMER_COUNT], uint64_t launches[PT_TIMER_COUNT]) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    for (int i = 0; i < PT_TIMER_COUNT; i++) {
+        if (ms) ms[i] = c->timer_ms[i];
+        if (launches) launches[i] = c->timer_launches[i];
+    }
+    return PT_OK;
+}
+
+}  // extern "C"

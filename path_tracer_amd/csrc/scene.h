@@ -1,0 +1,84 @@
+// scene.h -- host-side scene data of the path tracer: mesh, materials, images, accelerator trees.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pt_math.h"
+
+namespace pt {
+
+enum MaterialType { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_GLASS = 2 };
+
+// Render-time material state; defaults of src/cs488.h:372-387.
+struct HostMaterial {
+    std::string name;  // keeps the trailing newline of its "newmtl" line (src/cs488.h:868-871)
+    int type = MAT_LAMBERTIAN;
+    float eta = 1.0f;
+    vec3 Ka = {0.0f, 0.0f, 0.0f};
+    vec3 Kd = {0.9f, 0.9f, 0.9f};
+    vec3 Ks = {0.0f, 0.0f, 0.0f};
+    vec3 Ke = {0.0f, 0.0f, 0.0f};
+    float Ns = 0.0f;
+    float opacity = 1.0f;
+    float roughness = 0.6f;
+    bool textured = false;
+    std::string tex_path;
+    std::vector<uint8_t> tex;  // 3 bytes per texel, first image row first
+    int tex_w = 0, tex_h = 0;
+};
+
+// Triangle soup: every triangle owns its three vertices (the reference expands indexed faces the
+// same way, src/cs488.h:1138-1182).
+struct HostMesh {
+    std::vector<float> pos;  // 9 per triangle
+    std::vector<float> nrm;  // 9 per triangle
+    std::vector<float> uv;   // 6 per triangle
+    std::vector<int32_t> mat;
+    std::vector<HostMaterial> materials;
+    int num_tris() const { return (int)mat.size(); }
+    vec3 p(int tri, int k) const { return v3(pos[9 * tri + 3 * k], pos[9 * tri + 3 * k + 1], pos[9 * tri + 3 * k + 2]); }
+    void clear() { pos.clear(); nrm.clear(); uv.clear(); mat.clear(); materials.clear(); }
+};
+
+// Float RGB image, row 0 = bottom row (src/cs488.h:195-198, 208-215).
+struct HostImage {
+    std::vector<float> rgb;
+    int w = 0, h = 0;
+};
+
+// Accelerator as the CPU builders leave it, nodes in the reference's own order.
+struct HostTree {
+    struct Node {
+        float box[6];  // min xyz, max xyz
+        int32_t left = -1, right = -1;  // -1 on a leaf
+        int32_t first = 0, count = 0;   // leaf: range in refs
+    };
+    std::vector<Node> nodes;
+    std::vector<int32_t> refs;
+    int kind = 0;
+    int max_depth = 0;  // edges on the longest root-to-leaf path
+};
+
+// ---- loader.cpp ----
+// TriangleMesh::load (src/cs488.h:703-788).  false: file missing or no triangle in it.
+bool load_obj(const char* path, HostMesh& mesh, std::string& err);
+// TriangleMesh::createSingleTriangle (src/cs488.h:814-835)
+void make_single_triangle(HostMesh& mesh);
+
+// ---- image_io.cpp ----
+// Radiance RGBE (.hdr), flat or new-style RLE scanlines; output rows flipped to bottom-up.
+bool load_hdr(const char* path, HostImage& img, std::string& err);
+// Non-interlaced PNG of any colour type and bit depth, converted to 8-bit RGB.
+bool load_png_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
+bool save_png_rgb8(const char* path, const uint8_t* rgb, int w, int h, std::string& err);
+bool save_pfm(const char* path, const float* rgb_bottom_up, int w, int h, std::string& err);
+// Image::save quantisation (src/cs488.h:219-228): clamp to [0,1], scale by 255, truncate; rows top-down.
+void quantise_image(const float* rgb_bottom_up, int w, int h, std::vector<uint8_t>& out);
+
+// ---- accel_build.cpp ----
+void build_bvh(const HostMesh& mesh, HostTree& tree);  // src/cs488.h:1490-1667
+void build_kd(const HostMesh& mesh, HostTree& tree);   // src/cs488.h:1229-1320, 1388-1400
+
+}  // namespace pt

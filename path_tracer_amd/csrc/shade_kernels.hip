@@ -1,0 +1,476 @@
+// shade_kernels.hip -- camera-ray generation, material shading with ray-queue compaction, and
+// the accumulate / resolve stages of the wavefront path tracer (gfx950).
+//
+// The reference shades by recursion (shade, src/cs488.h:2149-2172); here every path carries a
+// throughput and each bounce is one pass over a queue.  With beta the product of the factors the
+// recursion would multiply onto the value returned from below:
+//   level > maxLevel             -> the path ends (src/cs488.h:2150)
+//   level > 4                    -> Russian roulette, survival leaves beta unchanged (:2153-2160)
+//   Lambertian (:2018-2048)      -> cos < eps ends the path with nothing added; otherwise
+//                                   radiance += beta*o*Ke, bounce child beta*o*(c*cos/p) whose miss
+//                                   adds env*p (miss_scale = p); if opacity o < 1-eps a second
+//                                   child continues straight through with beta*(1-o)
+//   metal (:2132-2147)           -> beta * (Kd*dot(L,N) + Ks*spec); ends if dot(L,N) < eps
+//   glass (:1926-1963)           -> beta unchanged; reflect on total internal reflection or when
+//                                   a uniform draw is below the Fresnel reflectance, else refract
+//                                   (the reference traces the refracted ray before deciding;
+//                                   here only the chosen ray is traced)
+//   miss                         -> radiance += beta * env(dir) * miss_scale (:1717-1727)
+// A path that ends with a non-finite throughput adds NaN to its sample, as the recursion's
+// 0 * NaN would; the accumulate stage drops samples with a NaN component but still counts them
+// (src/cs488.h:1841-1860).
+//
+// Random numbers are counter based: value = squares32(counter, key) with key derived from the
+// seed and the GLOBAL sample index and counter = pixel << 32 | path id << 8 | dimension, so an
+// image does not depend on how samples are split into batches or over GPUs.  Each draw is
+// turned into a float as the reference does, float(double(u32) / 2^32) (src/cs488.h:140-142).
+//
+// Surviving rays are appended to the next queue with one atomic per wave: ballot of the lanes
+// that emit, population count for the block of slots, prefix count for each lane's slot.
+#include <float.h>
+
+#include "device_types.h"
+#include "pt_math.h"
+
+namespace pt {
+
+namespace {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t squares32(uint64_t ctr, uint64_t key) {
+    uint64_t x = ctr * key, y = x, z = y + key;
+    x = x * x + y; x = (x >> 32) | (x << 32);
+    x = x * x + z; x = (x >> 32) | (x << 32);
+    x = x * x + y; x = (x >> 32) | (x << 32);
+    return (uint32_t)((x * x + z) >> 32);
+}
+
+struct Sampler {
+    uint64_t key;
+    uint64_t base;  // pixel << 32 | path id << 8
+    uint32_t dim;
+    __device__ __forceinline__ float next() {
+        const uint32_t u = squares32(base | (dim & 0xffu), key);
+        dim++;
+        return (float)((double)u / 4294967296.0);
+    }
+};
+
+__device__ __forceinline__ Sampler make_sampler(uint64_t seed, int global_sample, int pixel, uint32_t bits) {
+    Sampler s;
+    s.key = mix64(seed ^ mix64((uint64_t)(uint32_t)global_sample)) | 1ull;
+    s.base = ((uint64_t)(uint32_t)pixel << 32) | (uint64_t)(bits & 0xffffff00u);
+    s.dim = bits & 0xffu;
+    return s;
+}
+
+// slot -> (pixel, global sample index)
+__device__ __forceinline__ void slot_to_sample(const BatchGpu& b, int slot, int& pixel, int& sample) {
+    const int pl = slot / b.chunk;
+    pixel = b.pixel0 + pl;
+    sample = b.sample0 + (slot - pl * b.chunk);
+}
+
+// Appends one record per lane with pred set; returns the lane's index or -1.  Must be reached by
+// all lanes of the wave that are active at the call site together.
+__device__ __forceinline__ int queue_push(bool pred, int* counter, int cap, unsigned long long* counters) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0) return -1;
+    const int lane = __lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader);
+    const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
+    if (!pred) return -1;
+    if (idx >= cap) {
+        atomicMax(&counters[DC_OVERFLOW], 1ull);
+        return -1;
+    }
+    return idx;
+}
+
+__device__ __forceinline__ void add_radiance(float4* sample_rad, int slot, vec3 v) {
+    float* p = reinterpret_cast<float*>(sample_rad + slot);
+    atomicAdd(p + 0, v.x);
+    atomicAdd(p + 1, v.y);
+    atomicAdd(p + 2, v.z);
+}
+
+__device__ __forceinline__ bool finite3(vec3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+
+// Scene::ibl (src/cs488.h:1717-1727); the texel index is clamped where the reference would
+// index outside the image (direction along +-z).
+__device__ __forceinline__ vec3 env_lookup(const SceneGpu& sc, vec3 d) {
+    if (sc.env_h == 0) return v3(0.0f);
+    const float r = (1.0f / PT_PI) * acosf(d.z) / sqrtf((float)((double)d.x * (double)d.x + (double)d.y * (double)d.y));
+    const float u = d.x * r, v = d.y * r;
+    const float fi = (u + 1.0f) * 0.5f * sc.env_w;
+    const float fj = (v + 1.0f) * 0.5f * sc.env_h;
+    int i = (fi == fi) ? (int)fi : 0;
+    int j = (fj == fj) ? (int)fj : 0;
+    i = i < 0 ? 0 : (i > sc.env_w - 1 ? sc.env_w - 1 : i);
+    j = j < 0 ? 0 : (j > sc.env_h - 1 ? sc.env_h - 1 : j);
+    const float* p = sc.env + 3 * ((size_t)i + (size_t)j * sc.env_w);
+    return v3(p[0], p[1], p[2]);
+}
+
+__device__ __forceinline__ float saturate(float x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
+
+// -2 * dot(v, axis) * axis + v  (src/cs488.h:1912-1914)
+__device__ __forceinline__ vec3 reflect_about(vec3 v, vec3 axis) { return (-2 * dot(v, axis)) * axis + v; }
+
+struct Frame3 { vec3 cx, cy, cz; };
+__device__ __forceinline__ vec3 apply(const Frame3& m, vec3 v) { return m.cx * v.x + m.cy * v.y + m.cz * v.z; }
+__device__ __forceinline__ vec3 apply_transposed(const Frame3& m, vec3 v) {
+    // rows of the transpose are the columns of m; product formed column by column like the
+    // reference's mul(transpose(m), v) (src/linalg.h:536,557)
+    return v3(m.cx.x, m.cy.x, m.cz.x) * v.x + v3(m.cx.y, m.cy.y, m.cz.y) * v.y + v3(m.cx.z, m.cy.z, m.cz.z) * v.z;
+}
+// MakeRotationMatrix (src/cs488.h:2090-2098)
+__device__ __forceinline__ Frame3 frame_about(vec3 z) {
+    const vec3 ref = fabsf(dot(z, v3(0.0f, 1.0f, 0.0f))) > 0.99f ? v3(0.0f, 0.0f, 1.0f) : v3(0.0f, 1.0f, 0.0f);
+    Frame3 m;
+    m.cx = normalize(cross(ref, z));
+    m.cy = cross(z, m.cx);
+    m.cz = z;
+    return m;
+}
+
+// cosineWeightedHemisphereSample (src/cs488.h:1994-2016)
+__device__ __forceinline__ vec3 cosine_direction(vec3 w, float u1, float u2) {
+    const float r = sqrtf(u1);
+    const float theta = 2.0f * PT_PI * u2;
+    const float x = r * cosf(theta);
+    const float y = r * sinf(theta);
+    const float z = sqrtf(1.0f - u1);
+    const vec3 up = fabsf(w.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
+    const vec3 tg = normalize(cross(up, w));
+    const vec3 bt = cross(w, tg);
+    return normalize(tg * x + bt * y + w * z);
+}
+
+// sampleHalfVector (src/cs488.h:2100-2130)
+__device__ __forceinline__ vec3 half_vector(vec3 n, vec3 view, float rough, float ra, float rb) {
+    const Frame3 wfg = frame_about(n);
+    const float alpha = rough * rough;
+    const vec3 vg = apply_transposed(wfg, view);
+    const vec3 vs = normalize(v3(alpha * vg.x, alpha * vg.y, vg.z));
+    const float area_green = vs.z;
+    const float pb = 1 / (1.0f + area_green);
+    const float pg = 1 - pb;
+    const float phi = (rb < pb) ? rb / pb * PT_PI : PT_PI + (rb - pb) / pg * PT_PI;
+    const float r = sqrtf(ra);
+    const float x = r * cosf(phi);
+    const float y = r * sinf(phi) * (rb < pb ? 1.0f : area_green);
+    const float z = sqrtf(fmaxf(0.0f, 1.0f - x * x - y * y));
+    const vec3 ms = apply(frame_about(vs), v3(x, y, z));
+    const vec3 mg = v3(alpha * ms.x, alpha * ms.y, fmaxf(0.0f, ms.z));
+    return normalize(apply(wfg, mg));
+}
+
+// cookTorranceReflectance with schlickFresnel, normalDistributionGGX, geometricAttenuation
+// (src/cs488.h:2050-2088)
+__device__ __forceinline__ float cook_torrance(vec3 view, vec3 light, vec3 n, float rough, float eta) {
+    const vec3 hv = normalize(view + light);
+    const float nl = saturate(dot(n, light));
+    const float nv = saturate(dot(n, view));
+    const float nh = saturate(dot(n, hv));
+    const float vh = saturate(dot(view, hv));
+    const float es = eta - 1, ep = eta + 1;
+    const float f0 = (es * es) / (ep * ep);
+    const float F = f0 + (1 - f0) * powf(1 - vh, 5);
+    const float a = rough * rough;
+    const float a2 = a * a;
+    const float den = nh * nh * (a2 - 1.0f) + 1.0f;
+    const float D = a2 / (PT_PI * den * den);
+    const float g1 = 2 * nh * nv / vh;
+    const float g2 = 2 * nh * nl / vh;
+    const float G = fminf(1.0f, fminf(g1, g2));
+    const float spec = (F * D * G) / (4.0f * nv * nl + PT_EPSILON);
+    return saturate(spec);
+}
+
+// fresnel (src/cs488.h:1906-1910)
+__device__ __forceinline__ float fresnel_unpolarised(float e1, float e2, float ci, float co) {
+    const float rs = (e1 * ci - e2 * co) / (e1 * ci + e2 * co);
+    const float rt = (e1 * co - e2 * ci) / (e1 * co + e2 * ci);
+    return (powf(rs, 2) + powf(rt, 2)) / 2;
+}
+
+// Material::fetchTexture (src/cs488.h:402-414)
+__device__ __forceinline__ vec3 texel(const SceneGpu& sc, int tw, int th, int off, float u, float v) {
+    int x = int(u * tw) % tw;
+    int y = int(v * th) % th;
+    if (x < 0) x += tw;
+    if (y < 0) y += th;
+    const uint8_t* p = sc.texels + (size_t)off + 3 * ((size_t)x + (size_t)y * tw);
+    return v3((float)p[0], (float)p[1], (float)p[2]) / 255.0f;
+}
+
+// ---- camera rays: Scene::generateRay (src/cs488.h:1825-1839) ----
+__global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, QueueSet out, float4* __restrict__ sample_rad,
+                                                     int* __restrict__ qcount) {
+    const int stride = gridDim.x * blockDim.x;
+    const vec3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
+    const vec3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]), cw = v3(cam.w[0], cam.w[1], cam.w[2]);
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < b.n_slots; slot += stride) {
+        int pixel, sample;
+        slot_to_sample(b, slot, pixel, sample);
+        const int px = pixel % cam.width, py = pixel / cam.width;
+        Sampler rng = make_sampler(b.seed, sample, pixel, 1u << 8);
+        const float r1 = rng.next();
+        const float r2 = rng.next();
+        const float U = (px + (r1 * 2 - 1)) / float(cam.width) - 0.5f;
+        const float V = (py + (r2 * 2 - 1)) / float(cam.height) - 0.5f;
+        const vec3 pix = eye + float(cam.aspect_film * U) * cu + float(cam.film * V) * cv - cam.dist * cw;
+        const vec3 d = normalize(pix - eye);
+        out.ray_o[slot] = make_float4(eye.x, eye.y, eye.z, 1.0f);
+        out.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float((1u << 8) | rng.dim));
+        out.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(slot));
+        sample_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) qcount[0] = b.n_slots;
+}
+
+// ---- one bounce of shading for every path in the queue ----
+__global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int level, int max_level, QueueSet in,
+                                                    const float4* __restrict__ hit, QueueSet out,
+                                                    float4* __restrict__ sample_rad, int* __restrict__ qcount_in,
+                                                    int* __restrict__ qcount_out, unsigned long long* __restrict__ counters) {
+    const int n = *qcount_in;
+    const int stride = gridDim.x * blockDim.x;
+    for (int base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const int i = base + threadIdx.x;
+        bool emit0 = false, emit1 = false;
+        vec3 o0 = v3(0.0f), d0 = v3(0.0f), b0 = v3(0.0f);
+        vec3 o1 = v3(0.0f), d1 = v3(0.0f), b1 = v3(0.0f);
+        float scale0 = 1.0f;
+        uint32_t bits0 = 0, bits1 = 0;
+        int slot = 0;
+
+        if (i < n) {
+            const float4 ro = in.ray_o[i], rd = in.ray_d[i], bt = in.beta[i], h = hit[i];
+            const vec3 d = v3(rd.x, rd.y, rd.z);
+            const vec3 beta = v3(bt.x, bt.y, bt.z);
+            slot = __float_as_int(bt.w);
+            const uint32_t bits = __float_as_uint(rd.w);
+            const int tri = __float_as_int(h.x);
+            bool ended = false;  // path stops here without any contribution of its own
+
+            if (tri < 0) {
+                // miss: environment radiance (zero without a probe; the product keeps a NaN alive)
+                const vec3 e = env_lookup(sc, d) * ro.w;
+                if (sc.env_h != 0 || !finite3(beta)) add_radiance(sample_rad, slot, beta * e);
+            } else if (level > max_level) {
+                ended = true;
+            } else {
+                int pixel, sample;
+                slot_to_sample(b, slot, pixel, sample);
+                Sampler rng = make_sampler(b.seed, sample, pixel, bits);
+
+                // hit record: interpolated position, shading normal, texcoords (src/cs488.h:671-675)
+                const float hb = h.z, hg = h.w, ha = 1 - hb - hg;
+                const float4 P0 = sc.tri_pos[3 * tri], P1 = sc.tri_pos[3 * tri + 1], P2 = sc.tri_pos[3 * tri + 2];
+                const float4 N0 = sc.tri_nrm[3 * tri], N1 = sc.tri_nrm[3 * tri + 1], N2 = sc.tri_nrm[3 * tri + 2];
+                vec3 N = normalize(ha * v3(N0.x, N0.y, N0.z) + hb * v3(N1.x, N1.y, N1.z) + hg * v3(N2.x, N2.y, N2.z));
+                const vec3 P = ha * v3(P0.x, P0.y, P0.z) + hb * v3(P1.x, P1.y, P1.z) + hg * v3(P2.x, P2.y, P2.z);
+                const bool backface = dot(d, N) > 0;  // src/cs488.h:1770-1773
+                if (backface) N = -N;
+                const vec3 view = -d;
+
+                const int mid = __float_as_int(P0.w);
+                const float4 m0 = sc.mats[4 * mid], m1 = sc.mats[4 * mid + 1], m2 = sc.mats[4 * mid + 2], m3 = sc.mats[4 * mid + 3];
+                const int type = __float_as_int(m0.w);
+                const vec3 Kd = v3(m0.x, m0.y, m0.z), Ks = v3(m1.x, m1.y, m1.z), Ke = v3(m2.x, m2.y, m2.z);
+                const float eta = m1.w, opacity = m2.w, rough = m3.x;
+                const int tw = __float_as_int(m3.y), th = __float_as_int(m3.z), toff = __float_as_int(m3.w);
+
+                // HitInfo::surfaceColor (src/cs488.h:473-475), Lambertian only (Material::BRDF :417-428)
+                vec3 colour = v3(0.0f);
+                if (type == 0) {
+                    colour = Kd / PT_PI;
+                    if (tw > 0) {
+                        const float2 T0 = sc.tri_uv[3 * tri], T1 = sc.tri_uv[3 * tri + 1], T2 = sc.tri_uv[3 * tri + 2];
+                        const float tu = ha * T0.x + hb * T1.x + hg * T2.x;
+                        const float tv = ha * T0.y + hb * T1.y + hg * T2.y;
+                        colour = colour * texel(sc, tw, th, toff, tu, tv);
+                    }
+                }
+
+                bool alive = true;
+                if (level > 4) {  // Russian roulette, src/cs488.h:2153-2160
+                    float prob = 0.6f;
+                    if (type == 0) prob = fmaxf(fmaxf(colour.x, fmaxf(colour.y, colour.z)), 0.05f);
+                    if (rng.next() > prob) alive = false;
+                }
+                if (!alive) {
+                    ended = true;
+                } else if (type == 0) {
+                    const float u1 = rng.next();
+                    const float u2 = rng.next();
+                    const vec3 wo = cosine_direction(N, u1, u2);
+                    const float ct = dot(wo, N);
+                    if (ct < PT_EPSILON) {
+                        ended = true;
+                    } else {
+                        const float p = ct / PT_PI;
+                        const bool translucent = opacity < 1.0f - PT_EPSILON;
+                        const vec3 weight = translucent ? beta * opacity : beta;
+                        if (Ke.x != 0.0f || Ke.y != 0.0f || Ke.z != 0.0f) add_radiance(sample_rad, slot, weight * Ke);
+                        emit0 = true;
+                        o0 = P + PT_EPSILON * N;
+                        d0 = wo;
+                        b0 = weight * (colour * ct / p);
+                        scale0 = p;
+                        if (translucent) {
+                            emit1 = true;
+                            o1 = P - PT_EPSILON * N;
+                            d1 = d;
+                            b1 = beta * (1 - opacity);
+                        }
+                    }
+                } else if (type == 1) {
+                    const float ra = rng.next();
+                    const float rb = rng.next();
+                    const vec3 hv = half_vector(N, view, rough, ra, rb);
+                    const vec3 light = normalize(reflect_about(-view, hv));
+                    const float ln = dot(light, N);
+                    if (ln < PT_EPSILON) {
+                        ended = true;
+                    } else {
+                        const float spec = cook_torrance(view, light, N, rough, eta);
+                        emit0 = true;
+                        o0 = P + PT_EPSILON * N;
+                        d0 = light;
+                        b0 = beta * (Kd * ln + Ks * spec);
+                    }
+                } else if (type == 2) {
+                    const vec3 wi = d;
+                    const float wn = dot(wi, N);
+                    const float e1 = backface ? eta : PT_ETA_AIR, e2 = backface ? PT_ETA_AIR : eta;
+                    const float under = 1 - powf(e1 / e2, 2) * (1 - powf(wn, 2));
+                    bool reflect = under < 0;
+                    vec3 rdir = v3(0.0f);
+                    if (!reflect) {
+                        rdir = (e1 / e2) * (wi - wn * N) - (sqrtf(under) * N);
+                        const float ci = wn / (length(wi) * length(N));
+                        const float co = dot(N, rdir) / (length(N) * length(rdir));
+                        const float R = fresnel_unpolarised(e1, e2, ci, co);
+                        if (rng.next() < R) reflect = true;
+                    }
+                    emit0 = true;
+                    b0 = beta;
+                    if (reflect) {
+                        d0 = reflect_about(wi, N);
+                        o0 = P + PT_EPSILON * N;
+                    } else {
+                        d0 = rdir;
+                        o0 = P - PT_EPSILON * N;
+                    }
+                } else {
+                    // unknown material type: the reference's error colour (src/cs488.h:2170)
+                    add_radiance(sample_rad, slot, beta * v3(100.0f, 0.0f, 100.0f));
+                }
+
+                // random-number bookkeeping of the children: a fork doubles the path id
+                const uint32_t pid = bits >> 8;
+                if (emit1) {
+                    bits0 = (((pid << 1) & 0xffffffu) << 8);
+                    bits1 = ((((pid << 1) | 1u) & 0xffffffu) << 8);
+                } else {
+                    bits0 = (pid << 8) | (rng.dim & 0xffu);
+                }
+            }
+            if (ended && !finite3(beta)) add_radiance(sample_rad, slot, v3(NAN));
+        }
+
+        const int k0 = queue_push(emit0, qcount_out, b.cap, counters);
+        if (k0 >= 0) {
+            out.ray_o[k0] = make_float4(o0.x, o0.y, o0.z, scale0);
+            out.ray_d[k0] = make_float4(d0.x, d0.y, d0.z, __uint_as_float(bits0));
+            out.beta[k0] = make_float4(b0.x, b0.y, b0.z, __int_as_float(slot));
+        }
+        const int k1 = queue_push(emit1, qcount_out, b.cap, counters);
+        if (k1 >= 0) {
+            out.ray_o[k1] = make_float4(o1.x, o1.y, o1.z, 1.0f);
+            out.ray_d[k1] = make_float4(d1.x, d1.y, d1.z, __uint_as_float(bits1));
+            out.beta[k1] = make_float4(b1.x, b1.y, b1.z, __int_as_float(slot));
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&counters[DC_MAXQ], (unsigned long long)n);
+}
+
+// ---- per pixel: add the batch's samples to the accumulation buffer (src/cs488.h:1854-1858) ----
+__global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float4* __restrict__ sample_rad,
+                                                         float* __restrict__ accum, unsigned long long* __restrict__ counters) {
+    const int stride = gridDim.x * blockDim.x;
+    unsigned int dropped = 0;
+    for (int pl = blockIdx.x * blockDim.x + threadIdx.x; pl < b.n_pixels; pl += stride) {
+        float* dst = accum + 3 * (size_t)(b.pixel0 + pl);
+        float ax = dst[0], ay = dst[1], az = dst[2];
+        const float4* src = sample_rad + (size_t)pl * b.chunk;
+        for (int k = 0; k < b.chunk; k++) {
+            const float4 s = src[k];
+            if (isnan(s.x) || isnan(s.y) || isnan(s.z)) {
+                dropped++;
+            } else {
+                ax += s.x; ay += s.y; az += s.z;
+            }
+        }
+        dst[0] = ax; dst[1] = ay; dst[2] = az;
+    }
+    if (dropped) atomicAdd(&counters[DC_NAN], (unsigned long long)dropped);
+}
+
+// frame = accumulation / totalSamples (src/cs488.h:1860)
+__global__ void resolve_kernel(const float* __restrict__ accum, float* __restrict__ frame, size_t n, int total) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float div = (float)total;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) frame[i] = accum[i] / div;
+}
+
+__global__ void clear_kernel(float* buf, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) buf[i] = 0.0f;
+}
+
+}  // namespace
+
+hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const BatchGpu& batch, QueueSet out,
+                         float4* sample_rad, int* qcount) {
+    hipLaunchKernelGGL(raygen_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, cam, batch, out, sample_rad, qcount);
+    return hipGetLastError();
+}
+
+hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
+                        QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, int* qcount_in,
+                        int* qcount_out, unsigned long long* counters) {
+    hipLaunchKernelGGL(shade_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit,
+                       out, sample_rad, qcount_in, qcount_out, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const float4* sample_rad, float* accum,
+                             unsigned long long* counters) {
+    hipLaunchKernelGGL(accumulate_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, batch, sample_rad, accum, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const LaunchCfg& cfg, const float* accum, float* frame, int n_pixels, int total_samples) {
+    hipLaunchKernelGGL(resolve_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, accum, frame, (size_t)n_pixels * 3, total_samples);
+    return hipGetLastError();
+}
+
+hipError_t launch_clear(const LaunchCfg& cfg, float* buf, size_t n) {
+    hipLaunchKernelGGL(clear_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, buf, n);
+    return hipGetLastError();
+}
+
+}  // namespace pt
