@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Benchmark of the path tracer's hot path (one Scene::Pathtrace frame) on N MI355X GPUs.
+
+A step is one progressive frame: `spp` new samples for every pixel of the image, traced and shaded
+by the wavefront HIP kernels and added to the accumulation buffer.  The default workload is the
+reference's Cornell box (area light, Lambertian global illumination) at 1024x1024 with the
+reference's 10 samples per pixel per frame, SAH BVH traversal.
+
+With N > 1 (one process per GPU, launched by torch.distributed.run) every rank renders its own
+`spp` samples of a frame that adds N*spp samples per pixel (sample split, weak scaling) and the
+per-frame accumulation buffers are summed onto rank 0 with one RCCL reduce.
+
+Prints one JSON line on rank 0; see README / DESIGN.md for the fields.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+
+WORKLOADS = {
+    # name: (obj, needs probe)
+    "cornellbox": ("cornellbox.obj", False),
+    "cornellbox-glass": ("cornellbox-glass.obj", True),
+    "cornellbox-metal": ("cornellbox-metal.obj", True),
+    "cornellbox-alpha": ("cornellbox-alpha.obj", True),
+    "cornellball-glass": ("cornellball-glass.obj", False),
+    "teapot": ("teapot.obj", True),
+}
+
+
+def bytes_per_ray(n_box, n_tri, hit_frac, textured=False):
+    """Algorithmic bytes one closest-hit query moves: 24 B per slab test (6 floats), 36 B per
+    triangle test (9 floats), 48 B of normals + material id for a winning hit, 160 B of wavefront
+    state (ray 32 B + hit record 16 B + path state 32 B, each written once and read once)."""
+    return 24.0 * n_box + 36.0 * n_tri + 48.0 * hit_frac + 160.0
+
+
+def make_scene(pta, args, device, accel):
+    from common import scene_path
+    obj, needs_probe = WORKLOADS[args.workload]
+    s = pta.Scene(device)
+    if args.obj:
+        if not s.load(args.obj):
+            raise SystemExit("cannot load %s" % args.obj)
+        if args.hdr:
+            s.load_env(args.hdr)
+    else:
+        if not s.load(scene_path(obj)):
+            raise SystemExit("cannot load %s" % obj)
+        if needs_probe:
+            s.load_env(probe_path(args))
+    s.pre_calc(accel)
+    s.set_resolution(args.width, args.height)
+    return s
+
+
+def probe_path(args):
+    """512x512 synthetic probe (the reference's uffizi probe is not distributed), written once."""
+    from make_probe import probe_pixels, write_hdr
+    path = os.path.join(ROOT, "gpurun_out", "bench_probe_512.hdr")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    if not os.path.exists(path):
+        tmp = path + ".%d.tmp" % os.getpid()
+        write_hdr(tmp, probe_pixels(512, 1))
+        os.replace(tmp, path)
+    return path
+
+
+def cpu_baseline(args):
+    """The CPU restatement of the reference's multithreaded loop (column strips, one thread per
+    strip), timed on this host on a bounded sample of the same workload."""
+    import orc
+    from common import load_oracle_scene, read_hdr_independent
+    obj, needs_probe = WORKLOADS[args.workload]
+    cores = min(16, os.cpu_count() or 1)
+    o = load_oracle_scene(obj, orc.BVH if args.accel == "bvh" else orc.KD)
+    if needs_probe:
+        o.set_env(read_hdr_independent(probe_path(args)))
+    o.reset(args.width, args.height)
+    o.render(spp=1, frames=1, threads=cores)  # warm-up
+    o.reset(args.width, args.height)
+    frames, t0, rays = 0, time.time(), 0
+    while True:
+        _, _, cnt = o.render(spp=args.spp, frames=1, threads=cores)
+        rays += int(cnt[0])
+        frames += 1
+        dt = time.time() - t0
+        if dt > 10.0 or frames >= 5:
+            break
+    return {
+        "value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "spp_per_s": frames * args.spp / dt,
+        "sample": "%d frame(s) of the same %dx%d x %d spp workload, %d threads over column strips" % (
+            frames, args.width, args.height, args.spp, cores),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cornellbox", choices=sorted(WORKLOADS))
+    ap.add_argument("--obj", default=None, help="render this .obj instead of a named workload")
+    ap.add_argument("--hdr", default=None)
+    ap.add_argument("--accel", default="bvh", choices=["bvh", "kd"])
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=10, help="samples per pixel per frame and per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kd", action="store_true", help="skip the short kd-tree comparison run")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import path_tracer_amd as pta
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    accel = pta.BVH if args.accel == "bvh" else pta.KD
+    scene = make_scene(pta, args, local_rank, accel)
+    stream = torch.cuda.current_stream()
+    scene.set_stream(stream.cuda_stream)
+    n_pix = args.width * args.height
+
+    delta = master = None
+    if world > 1:
+        delta = torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda")
+        master = torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+        scene.use_external_accum(delta.data_ptr())
+
+    def step():
+        if world == 1:
+            scene.pathtrace(args.spp)
+        else:
+            delta.zero_()
+            scene.pathtrace_split(args.spp * world, rank * args.spp, args.spp)
+            dist.reduce(delta, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                master.add_(delta)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed counted pass: slab and triangle tests per ray for the roofline's byte count
+    scene.set_option(pta.OPT_COUNT_TESTS, 1)
+    scene.reset_counters()
+    step()
+    scene.synchronize()
+    c = scene.counters()
+    n_box = c[pta.CNT_BOX_TESTS] / max(c[pta.CNT_RAYS], 1)
+    n_tri = c[pta.CNT_TRI_TESTS] / max(c[pta.CNT_RAYS], 1)
+    hit_frac = c[pta.CNT_HITS] / max(c[pta.CNT_RAYS], 1)
+    scene.set_option(pta.OPT_COUNT_TESTS, 0)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    scene.reset_counters()
+    scene.set_option(pta.OPT_PROFILE, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    scene.set_option(pta.OPT_PROFILE, 0)
+    c = scene.counters()
+    ms, launches = scene.timers()
+    rays_local = float(c[pta.CNT_RAYS])
+    max_queue = c[pta.CNT_MAX_QUEUE]
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_total = float(r.item())
+    else:
+        rays_total = rays_local
+
+    out = None
+    if rank == 0:
+        b_ray = bytes_per_ray(n_box, n_tri, hit_frac)
+        trace_s = ms[pta.TIMER_TRACE] * 1e-3
+        achieved = rays_local * b_ray / trace_s * 1e-9 if trace_s > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": rays_total / elapsed * 1e-6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if WORKLOADS[args.workload][1] else "reference scene file",
+            "config": {
+                "workload": "%s %dx%d, %d spp/frame/GPU, SAH %s, progressive" % (
+                    args.obj or WORKLOADS[args.workload][0], args.width, args.height, args.spp, args.accel.upper()),
+                "parallelism": "sample-split x%d + RCCL reduce of the accumulation buffer" % world if world > 1 else "single GPU",
+            },
+            "spp_per_s": args.spp * world * args.steps / elapsed,
+            "rays_per_sample": rays_local / (float(n_pix) * args.spp * args.steps),
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "trace_kernel (closest hit)", "bytes_per_ray": b_ray,
+                "box_tests_per_ray": n_box, "tri_tests_per_ray": n_tri, "hit_fraction": hit_frac,
+                "launches": launches[pta.TIMER_TRACE], "avg_launch_ms": ms[pta.TIMER_TRACE] / max(launches[pta.TIMER_TRACE], 1),
+                "rays_per_launch": rays_local / max(launches[pta.TIMER_TRACE], 1),
+            },
+            "stage_ms_per_step": {
+                "raygen": ms[pta.TIMER_RAYGEN] / args.steps, "trace": ms[pta.TIMER_TRACE] / args.steps,
+                "shade": ms[pta.TIMER_SHADE] / args.steps, "accumulate": ms[pta.TIMER_ACCUM] / args.steps,
+            },
+            "max_queue": max_queue,
+        }
+
+    if world == 1 and rank == 0:
+        if not args.no_kd and args.accel == "bvh":
+            kd = make_scene(pta, args, local_rank, pta.KD)
+            kd.set_stream(stream.cuda_stream)
+            for _ in range(2):
+                kd.pathtrace(args.spp)
+            kd.synchronize()
+            kd.reset_counters()
+            k0 = time.perf_counter()
+            n_kd = max(3, args.steps // 3)
+            for _ in range(n_kd):
+                kd.pathtrace(args.spp)
+            kd.synchronize()
+            k1 = time.perf_counter() - k0
+            out["kd_tree"] = {"Mrays/s": kd.counters()[pta.CNT_RAYS] / k1 * 1e-6, "spp_per_s": n_kd * args.spp / k1, "steps": n_kd}
+            kd.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    scene.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -92,8 +92,9 @@ struct PtContext {
     float* ext_accum = nullptr;
     DeviceBuffer<float4> q_ray_o[2], q_ray_d[2], q_beta[2], d_hit, d_sample_rad;
     DeviceBuffer<int> d_qcount;
-    DeviceBuffer<unsigned long long> d_counters;
+    DeviceBuffer<unsigned long long> d_totals, d_block_stats;
     size_t batch_alloc = 0;
+    uint64_t batch_rays = 0;  // rays traced through pt_trace_batch
 
     // measurement
     uint64_t samples_started = 0;
@@ -332,12 +333,34 @@ int ensure_queues(PtContext* c, size_t batch) {
     return PT_OK;
 }
 
+// per-workgroup statistics summed on the host; the stream must be idle
+int read_block_stats(PtContext* c, unsigned long long out[DC_BLOCK_COUNT]) {
+    std::vector<unsigned long long> h((size_t)c->blocks * DC_BLOCK_COUNT);
+    PT_HIP(c, hipMemcpy(h.data(), c->d_block_stats.ptr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < DC_BLOCK_COUNT; k++) out[k] = 0;
+    for (int b = 0; b < c->blocks; b++)
+        for (int k = 0; k < DC_BLOCK_COUNT; k++) out[k] += h[(size_t)b * DC_BLOCK_COUNT + k];
+    return PT_OK;
+}
+
+int clear_block_stats(PtContext* c, bool overflow_only) {
+    if (!overflow_only) {
+        PT_HIP(c, hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)));
+        return PT_OK;
+    }
+    std::vector<unsigned long long> h((size_t)c->blocks * DC_BLOCK_COUNT);
+    PT_HIP(c, hipMemcpy(h.data(), c->d_block_stats.ptr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int b = 0; b < c->blocks; b++) h[(size_t)b * DC_BLOCK_COUNT + DB_OVERFLOW] = 0;
+    PT_HIP(c, hipMemcpy(c->d_block_stats.ptr, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
 int check_device_flags(PtContext* c) {
-    unsigned long long ov = 0;
-    PT_HIP(c, hipMemcpy(&ov, c->d_counters.ptr + DC_OVERFLOW, sizeof(ov), hipMemcpyDeviceToHost));
-    if (ov) {
-        unsigned long long zero = 0;
-        (void)hipMemcpy(c->d_counters.ptr + DC_OVERFLOW, &zero, sizeof(zero), hipMemcpyHostToDevice);
+    unsigned long long st[DC_BLOCK_COUNT];
+    int rc = read_block_stats(c, st);
+    if (rc != PT_OK) return rc;
+    if (st[DB_OVERFLOW]) {
+        (void)clear_block_stats(c, true);
         return fail(c, PT_ERR_QUEUE_OVERFLOW, "ray queue overflow: paths were dropped; raise PT_OPT_QUEUE_FACTOR");
     }
     return PT_OK;
@@ -349,11 +372,16 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     b.pixel0 = pixel0; b.n_pixels = n_pixels; b.chunk = chunk; b.sample0 = sample0;
     b.seed = c->seed;
     b.n_slots = n_pixels * chunk;
-    b.cap = (int)(c->batch_alloc * (size_t)c->queue_factor);
+    // workgroups sharing the batch: about 2048 camera samples each, at most the resident grid
+    int nb = (b.n_slots + 2047) / 2048;
+    nb = nb < 1 ? 1 : (nb > c->blocks ? c->blocks : nb);
+    b.blocks = nb;
+    b.slots_block = (b.n_slots + nb - 1) / nb;
+    b.cap_block = (int)((c->batch_alloc * (size_t)c->queue_factor) / (size_t)nb);
     const LaunchCfg cfg = cfg_of(c);
     const int levels = c->max_level + 2;  // levels 0 .. maxLevel+1; the last one only resolves misses
-    PT_HIP(c, c->d_qcount.ensure((size_t)levels + 1));
-    PT_HIP(c, hipMemsetAsync(c->d_qcount.ptr, 0, sizeof(int) * ((size_t)levels + 1), c->stream));
+    // every stage writes every workgroup's count of the next level, so the counts need no clearing
+    PT_HIP(c, c->d_qcount.ensure(((size_t)levels + 1) * (size_t)c->blocks));
     QueueSet q[2];
     for (int k = 0; k < 2; k++) { q[k].ray_o = c->q_ray_o[k].ptr; q[k].ray_d = c->q_ray_d[k].ptr; q[k].beta = c->q_beta[k].ptr; }
     {
@@ -366,17 +394,19 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
         {
             ScopedTimer tm(c, PT_TIMER_TRACE);
             PT_HIP(c, launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, in.ray_o, in.ray_d,
-                                   c->d_hit.ptr, c->d_qcount.ptr + level, 0, c->d_counters.ptr));
+                                   c->d_hit.ptr, c->d_qcount.ptr + (size_t)level * nb, 0, nb, b.cap_block, c->d_block_stats.ptr));
         }
         {
             ScopedTimer tm(c, PT_TIMER_SHADE);
             PT_HIP(c, launch_shade(cfg, c->scene, b, level, c->max_level, in, c->d_hit.ptr, out, c->d_sample_rad.ptr,
-                                   c->d_qcount.ptr + level, c->d_qcount.ptr + level + 1, c->d_counters.ptr));
+                                   c->d_qcount.ptr + (size_t)level * nb, c->d_qcount.ptr + (size_t)(level + 1) * nb,
+                                   c->d_block_stats.ptr));
         }
     }
     {
         ScopedTimer tm(c, PT_TIMER_ACCUM);
-        PT_HIP(c, launch_accumulate(cfg, b, c->d_sample_rad.ptr, c->accum_ptr(), c->d_counters.ptr));
+        PT_HIP(c, launch_accumulate(cfg, b, c->d_sample_rad.ptr, c->accum_ptr(), c->d_totals.ptr));
+        PT_HIP(c, launch_tally(cfg, c->d_qcount.ptr, levels, nb, c->d_totals.ptr));
     }
     c->samples_started += (uint64_t)b.n_slots;
     return PT_OK;
@@ -434,7 +464,9 @@ int pt_create(int device, PtContext** out) {
     c->own_stream = true;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->blocks = prop.multiProcessorCount * 8;
-    if (c->d_counters.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_counters.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess) {
+    if (c->d_totals.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+        c->d_block_stats.ensure((size_t)c->blocks * DC_BLOCK_COUNT) != hipSuccess ||
+        hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)) != hipSuccess) {
         pt_destroy(c);
         return PT_ERR_HIP;
     }
@@ -452,7 +484,7 @@ void pt_destroy(PtContext* c) {
     c->d_nodes.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
     c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
     for (int k = 0; k < 2; k++) { c->q_ray_o[k].release(); c->q_ray_d[k].release(); c->q_beta[k].release(); }
-    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_counters.release();
+    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -768,11 +800,15 @@ int pt_trace_batch(PtContext* c, int n, const float* rays6, int32_t* tri, float*
         PT_HIP(c, d_tri.ensure(n)); PT_HIP(c, d_t.ensure(n)); PT_HIP(c, d_bary.ensure(2 * (size_t)n));
         const LaunchCfg cfg = cfg_of(c);
         PT_HIP(c, launch_pack_rays(cfg, d_rays.ptr, n, d_o.ptr, d_d.ptr));
+        int nb = (n + 255) / 256;
+        nb = nb > c->blocks ? c->blocks : nb;
+        const int cap_block = (n + nb - 1) / nb;
         {
             ScopedTimer tm(c, PT_TIMER_TRACE);
             PT_HIP(c, launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, d_o.ptr, d_d.ptr, d_h.ptr,
-                                   nullptr, n, c->d_counters.ptr));
+                                   nullptr, n, nb, cap_block, c->d_block_stats.ptr));
         }
+        c->batch_rays += (uint64_t)n;
         PT_HIP(c, launch_unpack_hits(cfg, d_h.ptr, n, d_tri.ptr, d_t.ptr, d_bary.ptr));
         PT_HIP(c, hipMemcpyAsync(tri, d_tri.ptr, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         PT_HIP(c, hipMemcpyAsync(t, d_t.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
@@ -813,15 +849,17 @@ int pt_get_counters(PtContext* c, uint64_t out[PT_CNT_COUNT]) {
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     int rc = pt_synchronize(c);
     if (rc != PT_OK) return rc;
-    unsigned long long d[DC_COUNT];
-    PT_HIP(c, hipMemcpy(d, c->d_counters.ptr, sizeof(d), hipMemcpyDeviceToHost));
+    unsigned long long d[DC_COUNT], st[DC_BLOCK_COUNT];
+    PT_HIP(c, hipMemcpy(d, c->d_totals.ptr, sizeof(d), hipMemcpyDeviceToHost));
+    rc = read_block_stats(c, st);
+    if (rc != PT_OK) return rc;
     memset(out, 0, sizeof(uint64_t) * PT_CNT_COUNT);
-    out[PT_CNT_RAYS] = d[DC_RAYS];
-    out[PT_CNT_BOX_TESTS] = d[DC_BOX];
-    out[PT_CNT_TRI_TESTS] = d[DC_TRI];
+    out[PT_CNT_RAYS] = d[DC_RAYS] + c->batch_rays;
+    out[PT_CNT_BOX_TESTS] = st[DB_BOX];
+    out[PT_CNT_TRI_TESTS] = st[DB_TRI];
     out[PT_CNT_SAMPLES] = c->samples_started;
     out[PT_CNT_NAN_SAMPLES] = d[DC_NAN];
-    out[PT_CNT_HITS] = d[DC_HITS];
+    out[PT_CNT_HITS] = st[DB_HITS];
     out[PT_CNT_MAX_QUEUE] = d[DC_MAXQ];
     return PT_OK;
 }
@@ -831,8 +869,11 @@ int pt_reset_counters(PtContext* c) {
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     PT_HIP(c, hipStreamSynchronize(c->stream));
     drain_spans(c);
-    PT_HIP(c, hipMemset(c->d_counters.ptr, 0, DC_COUNT * sizeof(unsigned long long)));
+    PT_HIP(c, hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)));
+    int rc = clear_block_stats(c, false);
+    if (rc != PT_OK) return rc;
     c->samples_started = 0;
+    c->batch_rays = 0;
     for (int i = 0; i < PT_TIMER_COUNT; i++) { c->timer_ms[i] = 0; c->timer_launches[i] = 0; }
     return PT_OK;
 }

@@ -25,8 +25,9 @@
 // image does not depend on how samples are split into batches or over GPUs.  Each draw is
 // turned into a float as the reference does, float(double(u32) / 2^32) (src/cs488.h:140-142).
 //
-// Surviving rays are appended to the next queue with one atomic per wave: ballot of the lanes
-// that emit, population count for the block of slots, prefix count for each lane's slot.
+// Surviving rays are appended to the workgroup's own region of the next queue: ballot of the
+// lanes that emit, population count for the wave's block of entries (one LDS atomic per wave),
+// prefix count for each lane's entry.  No global atomic is involved.
 #include <float.h>
 
 #include "device_types.h"
@@ -77,23 +78,19 @@ __device__ __forceinline__ void slot_to_sample(const BatchGpu& b, int slot, int&
     sample = b.sample0 + (slot - pl * b.chunk);
 }
 
-// Appends one record per lane with pred set; returns the lane's index or -1.  Must be reached by
-// all lanes of the wave that are active at the call site together.
-__device__ __forceinline__ int queue_push(bool pred, int* counter, int cap, unsigned long long* counters) {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0) return -1;
+// Reserves queue entries for the lanes of one wave: every lane passes how many records it emits
+// first (0/1) and second (0/1); the wave takes one block of the workgroup's LDS counter and each
+// lane gets its two indices (relative to the workgroup's region).  Must be reached by all 64 lanes.
+__device__ __forceinline__ void wave_reserve(bool e0, bool e1, int* lds_counter, int& idx0, int& idx1) {
+    const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1);
     const int lane = __lane_id();
-    const int leader = __ffsll((long long)mask) - 1;
+    const int c0 = __popcll(m0), c1 = __popcll(m1);
     int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-    base = __shfl(base, leader);
-    const int idx = base + __popcll(mask & ((1ull << lane) - 1ull));
-    if (!pred) return -1;
-    if (idx >= cap) {
-        atomicMax(&counters[DC_OVERFLOW], 1ull);
-        return -1;
-    }
-    return idx;
+    if (lane == 0 && (c0 + c1) > 0) base = atomicAdd(lds_counter, c0 + c1);
+    base = __shfl(base, 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    idx0 = base + __popcll(m0 & below);
+    idx1 = base + c0 + __popcll(m1 & below);
 }
 
 __device__ __forceinline__ void add_radiance(float4* sample_rad, int slot, vec3 v) {
@@ -215,12 +212,19 @@ __device__ __forceinline__ vec3 texel(const SceneGpu& sc, int tw, int th, int of
 }
 
 // ---- camera rays: Scene::generateRay (src/cs488.h:1825-1839) ----
+// Workgroup b generates the camera samples [b*slots_block, (b+1)*slots_block) into its own region.
 __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, QueueSet out, float4* __restrict__ sample_rad,
                                                      int* __restrict__ qcount) {
-    const int stride = gridDim.x * blockDim.x;
+    const int blk = blockIdx.x;
+    const long long first = (long long)blk * b.slots_block;
+    const long long rest = (long long)b.n_slots - first;
+    const int n = rest <= 0 ? 0 : (rest < b.slots_block ? (int)rest : b.slots_block);
+    if (threadIdx.x == 0) qcount[blk] = n;
+    const size_t region = (size_t)blk * b.cap_block;
     const vec3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
     const vec3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]), cw = v3(cam.w[0], cam.w[1], cam.w[2]);
-    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < b.n_slots; slot += stride) {
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const int slot = (int)first + j;
         int pixel, sample;
         slot_to_sample(b, slot, pixel, sample);
         const int px = pixel % cam.width, py = pixel / cam.width;
@@ -231,23 +235,32 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
         const float V = (py + (r2 * 2 - 1)) / float(cam.height) - 0.5f;
         const vec3 pix = eye + float(cam.aspect_film * U) * cu + float(cam.film * V) * cv - cam.dist * cw;
         const vec3 d = normalize(pix - eye);
-        out.ray_o[slot] = make_float4(eye.x, eye.y, eye.z, 1.0f);
-        out.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float((1u << 8) | rng.dim));
-        out.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(slot));
+        out.ray_o[region + j] = make_float4(eye.x, eye.y, eye.z, 1.0f);
+        out.ray_d[region + j] = make_float4(d.x, d.y, d.z, __uint_as_float((1u << 8) | rng.dim));
+        out.beta[region + j] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(slot));
         sample_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) qcount[0] = b.n_slots;
 }
 
 // ---- one bounce of shading for every path in the queue ----
 __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int level, int max_level, QueueSet in,
                                                     const float4* __restrict__ hit, QueueSet out,
-                                                    float4* __restrict__ sample_rad, int* __restrict__ qcount_in,
-                                                    int* __restrict__ qcount_out, unsigned long long* __restrict__ counters) {
-    const int n = *qcount_in;
-    const int stride = gridDim.x * blockDim.x;
-    for (int base = blockIdx.x * blockDim.x; base < n; base += stride) {
-        const int i = base + threadIdx.x;
+                                                    float4* __restrict__ sample_rad, const int* __restrict__ qcount_in,
+                                                    int* __restrict__ qcount_out, unsigned long long* __restrict__ block_stats) {
+    __shared__ int s_out;
+    const int blk = blockIdx.x;
+    int n = qcount_in[blk];
+    n = n < b.cap_block ? n : b.cap_block;
+    if (n <= 0) {
+        if (threadIdx.x == 0) qcount_out[blk] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) s_out = 0;
+    __syncthreads();
+    const size_t region = (size_t)blk * b.cap_block;
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int j = base + threadIdx.x;
+        const size_t i = region + j;
         bool emit0 = false, emit1 = false;
         vec3 o0 = v3(0.0f), d0 = v3(0.0f), b0 = v3(0.0f);
         vec3 o1 = v3(0.0f), d1 = v3(0.0f), b1 = v3(0.0f);
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
         uint32_t bits0 = 0, bits1 = 0;
         int slot = 0;
 
-        if (i < n) {
+        if (j < n) {
             const float4 ro = in.ray_o[i], rd = in.ray_d[i], bt = in.beta[i], h = hit[i];
             const vec3 d = v3(rd.x, rd.y, rd.z);
             const vec3 beta = v3(bt.x, bt.y, bt.z);
@@ -391,25 +404,30 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
             if (ended && !finite3(beta)) add_radiance(sample_rad, slot, v3(NAN));
         }
 
-        const int k0 = queue_push(emit0, qcount_out, b.cap, counters);
-        if (k0 >= 0) {
-            out.ray_o[k0] = make_float4(o0.x, o0.y, o0.z, scale0);
-            out.ray_d[k0] = make_float4(d0.x, d0.y, d0.z, __uint_as_float(bits0));
-            out.beta[k0] = make_float4(b0.x, b0.y, b0.z, __int_as_float(slot));
+        int k0, k1;
+        wave_reserve(emit0, emit1, &s_out, k0, k1);
+        if (emit0 && k0 < b.cap_block) {
+            out.ray_o[region + k0] = make_float4(o0.x, o0.y, o0.z, scale0);
+            out.ray_d[region + k0] = make_float4(d0.x, d0.y, d0.z, __uint_as_float(bits0));
+            out.beta[region + k0] = make_float4(b0.x, b0.y, b0.z, __int_as_float(slot));
         }
-        const int k1 = queue_push(emit1, qcount_out, b.cap, counters);
-        if (k1 >= 0) {
-            out.ray_o[k1] = make_float4(o1.x, o1.y, o1.z, 1.0f);
-            out.ray_d[k1] = make_float4(d1.x, d1.y, d1.z, __uint_as_float(bits1));
-            out.beta[k1] = make_float4(b1.x, b1.y, b1.z, __int_as_float(slot));
+        if (emit1 && k1 < b.cap_block) {
+            out.ray_o[region + k1] = make_float4(o1.x, o1.y, o1.z, 1.0f);
+            out.ray_d[region + k1] = make_float4(d1.x, d1.y, d1.z, __uint_as_float(bits1));
+            out.beta[region + k1] = make_float4(b1.x, b1.y, b1.z, __int_as_float(slot));
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&counters[DC_MAXQ], (unsigned long long)n);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int produced = s_out;
+        qcount_out[blk] = produced < b.cap_block ? produced : b.cap_block;
+        if (produced > b.cap_block) block_stats[(size_t)blk * DC_BLOCK_COUNT + DB_OVERFLOW] = 1;  // paths were dropped
+    }
 }
 
 // ---- per pixel: add the batch's samples to the accumulation buffer (src/cs488.h:1854-1858) ----
 __global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float4* __restrict__ sample_rad,
-                                                         float* __restrict__ accum, unsigned long long* __restrict__ counters) {
+                                                         float* __restrict__ accum, unsigned long long* __restrict__ totals) {
     const int stride = gridDim.x * blockDim.x;
     unsigned int dropped = 0;
     for (int pl = blockIdx.x * blockDim.x + threadIdx.x; pl < b.n_pixels; pl += stride) {
@@ -426,7 +444,32 @@ __global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float
         }
         dst[0] = ax; dst[1] = ay; dst[2] = az;
     }
-    if (dropped) atomicAdd(&counters[DC_NAN], (unsigned long long)dropped);
+    if (dropped) atomicAdd(&totals[DC_NAN], (unsigned long long)dropped);
+}
+
+// Per level: total queue population of the batch = closest-hit queries of that level.
+__global__ __launch_bounds__(256) void tally_kernel(const int* __restrict__ qcount, int levels, int blocks,
+                                                    unsigned long long* __restrict__ totals) {
+    __shared__ unsigned long long s_sum[256];
+    unsigned long long rays = 0, peak = 0;
+    for (int level = 0; level < levels; level++) {
+        unsigned long long part = 0;
+        for (int k = threadIdx.x; k < blocks; k += blockDim.x) part += (unsigned long long)qcount[(size_t)level * blocks + k];
+        s_sum[threadIdx.x] = part;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+            __syncthreads();
+        }
+        const unsigned long long total = s_sum[0];
+        __syncthreads();
+        rays += total;
+        peak = total > peak ? total : peak;
+    }
+    if (threadIdx.x == 0) {
+        totals[DC_RAYS] += rays;
+        if (peak > totals[DC_MAXQ]) totals[DC_MAXQ] = peak;
+    }
 }
 
 // frame = accumulation / totalSamples (src/cs488.h:1860)
@@ -445,21 +488,26 @@ __global__ void clear_kernel(float* buf, size_t n) {
 
 hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const BatchGpu& batch, QueueSet out,
                          float4* sample_rad, int* qcount) {
-    hipLaunchKernelGGL(raygen_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, cam, batch, out, sample_rad, qcount);
+    hipLaunchKernelGGL(raygen_kernel, dim3(batch.blocks), dim3(256), 0, cfg.stream, cam, batch, out, sample_rad, qcount);
     return hipGetLastError();
 }
 
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
-                        QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, int* qcount_in,
-                        int* qcount_out, unsigned long long* counters) {
-    hipLaunchKernelGGL(shade_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit,
-                       out, sample_rad, qcount_in, qcount_out, counters);
+                        QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
+                        int* qcount_out, unsigned long long* block_stats) {
+    hipLaunchKernelGGL(shade_kernel, dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit,
+                       out, sample_rad, qcount_in, qcount_out, block_stats);
     return hipGetLastError();
 }
 
 hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const float4* sample_rad, float* accum,
-                             unsigned long long* counters) {
-    hipLaunchKernelGGL(accumulate_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, batch, sample_rad, accum, counters);
+                             unsigned long long* totals) {
+    hipLaunchKernelGGL(accumulate_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, batch, sample_rad, accum, totals);
+    return hipGetLastError();
+}
+
+hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, unsigned long long* totals) {
+    hipLaunchKernelGGL(tally_kernel, dim3(1), dim3(256), 0, cfg.stream, qcount, levels, blocks, totals);
     return hipGetLastError();
 }
 

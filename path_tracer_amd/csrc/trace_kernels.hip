@@ -18,8 +18,8 @@
 // This file is compiled with -ffp-contract=off: the x86 reference evaluates every product and
 // sum separately, and a fused multiply-add here would change low-order bits of t.
 //
-// Launch shape: a fixed grid of 256-lane workgroups strides over the queue, whose length is read
-// from device memory (written by the previous stage), so the host never waits for a count.
+// Launch shape: one 256-lane workgroup per queue region; the region's length is read from device
+// memory (written by the previous stage), so the host never waits for a count.
 // The first `lds_nodes` tree nodes (the top levels; nodes are numbered breadth-first) are copied
 // into LDS by every workgroup that has work.
 #include <float.h>
@@ -76,105 +76,114 @@ __device__ __forceinline__ void triangle_test(const SceneGpu& sc, int tri, vec3 
 template <bool KD, bool COUNT>
 __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
                                                     const float4* __restrict__ ray_d, float4* __restrict__ hit,
-                                                    const int* __restrict__ n_ptr, int n_fixed,
-                                                    unsigned long long* __restrict__ counters) {
+                                                    const int* __restrict__ n_ptr, int n_fixed, int cap_block,
+                                                    unsigned long long* __restrict__ block_stats) {
     extern __shared__ float4 lds_nodes[];
-    const int n = n_ptr ? *n_ptr : n_fixed;
-    const int stride = gridDim.x * blockDim.x;
-    if ((int)(blockIdx.x * blockDim.x) >= n) return;
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[4];  // 16 bytes: keeps the dynamic region 16-byte aligned
+    const int blk = blockIdx.x;
+    int n;
+    if (n_ptr) {
+        n = n_ptr[blk];
+        n = n < cap_block ? n : cap_block;
+    } else {
+        const long long rest = (long long)n_fixed - (long long)blk * cap_block;
+        n = rest <= 0 ? 0 : (rest < cap_block ? (int)rest : cap_block);
+    }
+    if (n <= 0) return;
+    const size_t region = (size_t)blk * cap_block;
 
     const int staged = sc.lds_nodes;
     for (int k = threadIdx.x; k < staged * 4; k += blockDim.x) lds_nodes[k] = sc.nodes[k];
-    if (staged > 0) __syncthreads();
+    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    __syncthreads();
 
     const vec3 rlo = v3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]);
     const vec3 rhi = v3(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2]);
     unsigned int n_box = 0, n_tri = 0, n_hit = 0;
 
-    for (int base = blockIdx.x * blockDim.x; base < n; base += stride) {
-        const int i = base + threadIdx.x;
-        if (i < n) {
-            const float4 ro = ray_o[i], rd = ray_d[i];
-            const vec3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);
-            Best best;
-            best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const size_t i = region + j;
+        const float4 ro = ray_o[i], rd = ray_d[i];
+        const vec3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);
+        Best best;
+        best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
 
-            int stack[TRACE_STACK];
-            float stack_t[KD ? TRACE_STACK : 1];
-            int sp = 0;
-            float t_root;
-            if (COUNT) n_box++;
-            bool walking = slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
-            int cur = sc.root_ref;
-            while (walking) {
-                if (cur < 0) {
-                    const int off = ~cur;
-                    const int cnt = sc.refs[off];
-                    for (int k = 1; k <= cnt; k++) {
-                        if (COUNT) n_tri++;
-                        triangle_test(sc, sc.refs[off + k], o, d, best);
-                    }
-                    cur = 0;
-                    walking = false;
+        int stack[TRACE_STACK];
+        float stack_t[KD ? TRACE_STACK : 1];
+        int sp = 0;
+        float t_root;
+        if (COUNT) n_box++;
+        bool walking = slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
+        int cur = sc.root_ref;
+        while (walking) {
+            if (cur < 0) {
+                const int off = ~cur;
+                const int cnt = sc.refs[off];
+                for (int k = 1; k <= cnt; k++) {
+                    if (COUNT) n_tri++;
+                    triangle_test(sc, sc.refs[off + k], o, d, best);
+                }
+                walking = false;
+            } else {
+                float4 q0, q1, q2, q3;
+                if (cur < staged) {
+                    q0 = lds_nodes[4 * cur]; q1 = lds_nodes[4 * cur + 1]; q2 = lds_nodes[4 * cur + 2]; q3 = lds_nodes[4 * cur + 3];
                 } else {
-                    float4 q0, q1, q2, q3;
-                    if (cur < staged) {
-                        q0 = lds_nodes[4 * cur]; q1 = lds_nodes[4 * cur + 1]; q2 = lds_nodes[4 * cur + 2]; q3 = lds_nodes[4 * cur + 3];
-                    } else {
-                        const float4* np = sc.nodes + 4 * (size_t)cur;
-                        q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
-                    }
-                    float tl, tr;
-                    if (COUNT) n_box += 2;
-                    bool hl = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tl);
-                    bool hr = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tr);
-                    hl = hl && (tl < best.t);
-                    hr = hr && (tr < best.t);
-                    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-                    if (hl && hr) {
-                        const bool left_first = tl < tr;
-                        stack[sp] = left_first ? right : left;
-                        if (KD) stack_t[sp] = left_first ? tr : tl;
-                        sp++;
-                        cur = left_first ? left : right;
-                        continue;
-                    } else if (hl) {
-                        cur = left;
-                        continue;
-                    } else if (hr) {
-                        cur = right;
-                        continue;
-                    }
-                    walking = false;
+                    const float4* np = sc.nodes + 4 * (size_t)cur;
+                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
                 }
-                // take the next deferred child
-                while (sp > 0) {
-                    sp--;
-                    if (KD && !(stack_t[sp] < best.t)) continue;
-                    cur = stack[sp];
-                    walking = true;
-                    break;
+                float tl, tr;
+                if (COUNT) n_box += 2;
+                bool hl = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tl);
+                bool hr = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tr);
+                hl = hl && (tl < best.t);
+                hr = hr && (tr < best.t);
+                const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+                if (hl && hr) {
+                    const bool left_first = tl < tr;
+                    stack[sp] = left_first ? right : left;
+                    if (KD) stack_t[sp] = left_first ? tr : tl;
+                    sp++;
+                    cur = left_first ? left : right;
+                    continue;
+                } else if (hl) {
+                    cur = left;
+                    continue;
+                } else if (hr) {
+                    cur = right;
+                    continue;
                 }
+                walking = false;
             }
-            if (best.tri >= 0) n_hit++;
-            hit[i] = make_float4(__int_as_float(best.tri), best.t, best.beta, best.gamma);
+            // take the next deferred child
+            while (sp > 0) {
+                sp--;
+                if (KD && !(stack_t[sp] < best.t)) continue;
+                cur = stack[sp];
+                walking = true;
+                break;
+            }
         }
+        if (best.tri >= 0) n_hit++;
+        hit[i] = make_float4(__int_as_float(best.tri), best.t, best.beta, best.gamma);
     }
 
-    // one atomic per wave and counter
+    // statistics: wave sums -> LDS -> this workgroup's own slots (no global atomics)
     unsigned int tot_hit = n_hit, tot_box = n_box, tot_tri = n_tri;
     for (int off = 32; off > 0; off >>= 1) {
         tot_hit += __shfl_down(tot_hit, off);
         if (COUNT) { tot_box += __shfl_down(tot_box, off); tot_tri += __shfl_down(tot_tri, off); }
     }
     if ((threadIdx.x & 63) == 0) {
-        if (tot_hit) atomicAdd(&counters[DC_HITS], (unsigned long long)tot_hit);
-        if (COUNT) {
-            atomicAdd(&counters[DC_BOX], (unsigned long long)tot_box);
-            atomicAdd(&counters[DC_TRI], (unsigned long long)tot_tri);
-        }
+        atomicAdd(&s_stat[0], tot_hit);
+        if (COUNT) { atomicAdd(&s_stat[1], tot_box); atomicAdd(&s_stat[2], tot_tri); }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[DC_RAYS], (unsigned long long)n);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* st = block_stats + (size_t)blk * DC_BLOCK_COUNT;
+        st[DB_HITS] += s_stat[0];
+        if (COUNT) { st[DB_BOX] += s_stat[1]; st[DB_TRI] += s_stat[2]; }
+    }
 }
 
 __global__ void pack_rays_kernel(const float* __restrict__ rays6, int n, float4* ray_o, float4* ray_d) {
@@ -200,16 +209,16 @@ __global__ void unpack_hits_kernel(const float4* __restrict__ hit, int n, int* t
 
 hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int count_tests, int fast_slab,
                         const float4* ray_o, const float4* ray_d, float4* hit, const int* n_rays, int n_fixed,
-                        unsigned long long* counters) {
+                        int grid_blocks, int cap_block, unsigned long long* block_stats) {
     (void)fast_slab;
     const size_t lds = (size_t)scene.lds_nodes * 64;
-    dim3 grid(cfg.blocks), block(256);
+    dim3 grid(grid_blocks), block(256);
     if (kd) {
-        if (count_tests) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, counters);
-        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, counters);
+        if (count_tests) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats);
+        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats);
     } else {
-        if (count_tests) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, counters);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, counters);
+        if (count_tests) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats);
     }
     return hipGetLastError();
 }
