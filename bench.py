@@ -143,21 +143,22 @@ def main():
     scene.set_stream(stream.cuda_stream)
     n_pix = args.width * args.height
 
-    delta = master = None
+    reducer = None
     if world > 1:
+        from path_tracer_amd.distributed import FrameReducer, sample_share
         delta = torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda")
         master = torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
         scene.use_external_accum(delta.data_ptr())
+        reducer = FrameReducer(dist, delta, master)
+        first, count = sample_share(args.spp * world, world, rank)
 
     def step():
         if world == 1:
             scene.pathtrace(args.spp)
         else:
-            delta.zero_()
-            scene.pathtrace_split(args.spp * world, rank * args.spp, args.spp)
-            dist.reduce(delta, dst=0, op=dist.ReduceOp.SUM)
-            if rank == 0:
-                master.add_(delta)
+            reducer.begin_frame()
+            scene.pathtrace_split(args.spp * world, first, count)
+            reducer.reduce(args.spp * world)
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,88 @@
+"""world_size-2 test of the sample-split exchange step on CPU tensors (gloo): two ranks render
+disjoint sample ranges of the same frames with the CPU oracle standing in for the GPU renderer,
+the per-frame accumulation buffers are reduced onto rank 0, and the result must equal a
+single-process accumulation of the same per-rank images."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _render_share(rank, frame, first, count, w, h):
+    """Accumulation of samples [first, first+count) of one frame; seeded by (frame, sample)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from common import load_oracle_scene
+    o = load_oracle_scene("cornellbox.obj", orc.BVH)
+    acc = np.zeros((h, w, 3), np.float32)
+    for s in range(first, first + count):
+        o.reset(w, h)
+        o.render(spp=1, frames=1, threads=1, state=(0x9E3779B97F4A7C15 * (1 + frame * 64 + s)) % (1 << 64) | 1)
+        acc += o.image("accum")
+    return acc
+
+
+def _worker(rank, world, port, spp_frame, frames, w, h, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from path_tracer_amd.distributed import FrameReducer, sample_share
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    delta = torch.zeros(h * w * 3, dtype=torch.float32)
+    master = torch.zeros(h * w * 3, dtype=torch.float32) if rank == 0 else None
+    red = FrameReducer(dist, delta, master)
+    first, count = sample_share(spp_frame, world, rank)
+    for f in range(frames):
+        red.begin_frame()
+        delta += torch.from_numpy(_render_share(rank, f, first, count, w, h).reshape(-1))
+        red.reduce(spp_frame)
+    if rank == 0:
+        np.save(out_path, red.frame().numpy().reshape(h, w, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sample_share_partitions():
+    sys.path.insert(0, ROOT)
+    from path_tracer_amd.distributed import sample_share
+    for spp in (0, 1, 7, 10, 4096):
+        for world in (1, 2, 3, 8):
+            got = [sample_share(spp, world, r) for r in range(world)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == spp
+            for (f0, c0), (f1, _) in zip(got, got[1:]):
+                assert f1 == f0 + c0
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    assert sample_share(4096, 8, 3) == (1536, 512)
+    with pytest.raises(ValueError):
+        sample_share(8, 2, 2)
+
+
+def test_two_rank_reduce_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    world, spp_frame, frames, w, h = 2, 3, 2, 32, 24
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), spp_frame, frames, w, h, out), nprocs=world, join=True)
+    got = np.load(out)
+    sys.path.insert(0, ROOT)
+    from path_tracer_amd.distributed import sample_share
+    want = np.zeros((h, w, 3), np.float32)
+    for f in range(frames):
+        parts = [_render_share(r, f, *sample_share(spp_frame, world, r), w, h) for r in range(world)]
+        want += parts[0] + parts[1]
+    want /= float(spp_frame * frames)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert got.mean() > 0.01

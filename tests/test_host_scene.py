@@ -1,0 +1,181 @@
+"""Host side of the product library without a GPU: .obj/.mtl loader and the two accelerator
+builders, compared with the oracle's independent restatement of the reference (bit for bit), and
+the loader's documented behaviours."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+import path_tracer_amd as pta
+from common import SCENES, scene_path
+
+OBJS = sorted(f for f in os.listdir(SCENES) if f.endswith(".obj"))
+
+
+def bits(a):
+    return a.view(np.uint32) if a.dtype == np.float32 else a
+
+
+def host_scene(obj=None):
+    s = pta.Scene(pta.DEVICE_NONE)
+    if obj:
+        assert s.load(scene_path(obj))
+    return s
+
+
+@pytest.mark.parametrize("obj", OBJS)
+def test_loader_matches_oracle(obj):
+    o = orc.Oracle()
+    n = o.load_obj(scene_path(obj))
+    s = host_scene(obj)
+    assert n == s.num_triangles() > 0
+    for a, b in zip(o.get_tris(), s.get_mesh()):
+        assert np.array_equal(bits(a), bits(b))
+    assert o.num_materials() == s.num_materials()
+    for ma, mb in zip(o.materials(), s.materials()):
+        for f in ("name", "type", "eta", "Ns", "opacity", "roughness", "textured"):
+            assert getattr(ma, f) == getattr(mb, f), f
+        for f in ("Ka", "Kd", "Ks", "Ke"):
+            assert list(getattr(ma, f)) == list(getattr(mb, f)), f
+
+
+@pytest.mark.parametrize("obj", [o for o in OBJS if o != "teapot.obj"])
+@pytest.mark.parametrize("accel", [orc.BVH, orc.KD])
+def test_builders_match_oracle(obj, accel):
+    compare_trees(obj, accel)
+
+
+def test_teapot_bvh_matches_oracle():
+    compare_trees("teapot.obj", orc.BVH)
+
+
+def test_teapot_kd_sweep_builder_matches_quadratic_oracle():
+    """The product finds each kd split by binary search in sorted extents; the oracle recounts
+    every triangle for every candidate like the reference.  Same tree, node for node."""
+    t = compare_trees("teapot.obj", orc.KD)
+    assert len(t["left"]) == 126015 and t["max_depth"] == 33
+
+
+def compare_trees(obj, accel):
+    o = orc.Oracle()
+    o.load_obj(scene_path(obj))
+    o.build(accel)
+    s = host_scene(obj)
+    s.pre_calc(accel)
+    t = s.get_tree()
+    if accel == orc.BVH:
+        d = o.bvh_dump()
+        leaf = d["is_leaf"] == 1
+        assert np.array_equal(np.where(leaf, -1, d["left"]), t["left"])
+        assert np.array_equal(np.where(leaf, -1, d["right"]), t["right"])
+    else:
+        d = o.kd_dump()
+        assert np.array_equal(d["left"], t["left"]) and np.array_equal(d["right"], t["right"])
+    assert np.array_equal(d["count"], t["count"])
+    assert np.array_equal(bits(d["box"]), bits(t["box"]))
+    for i in np.nonzero(d["count"])[0]:
+        assert np.array_equal(d["refs"][d["first"][i]:d["first"][i] + d["count"][i]],
+                              t["refs"][t["first"][i]:t["first"][i] + t["count"][i]]), i
+    # depth = longest root-to-leaf path
+    depth = np.zeros(len(t["left"]), np.int32)
+    for i in range(len(t["left"])):
+        for c in (t["left"][i], t["right"][i]):
+            if c >= 0:
+                depth[c] = depth[i] + 1
+    assert depth.max() == t["max_depth"]
+    return t
+
+
+def test_material_rules():
+    s = host_scene("cornellbox-glass.obj")
+    m = {x.name: x for x in s.materials()}
+    assert b"glass\n" in m, "names keep their newline"
+    g = m[b"glass\n"]
+    assert g.type == pta.GLASS and g.eta == 1.5 and g.Ns == 100.0  # the name beats Ns == 100
+    s = host_scene("cornellbox-metal.obj")
+    mt = {x.name: x for x in s.materials()}[b"metal\n"]
+    assert mt.type == pta.METAL and abs(mt.roughness - 0.7) < 1e-7 and abs(mt.eta - 1.2) < 1e-7
+    s = host_scene("cornellbox-alpha.obj")
+    a = {x.name: x for x in s.materials()}
+    assert abs(a[b"metalred\n"].opacity - 0.2) < 1e-7 and abs(a[b"metalblue\n"].opacity - 0.4) < 1e-7
+    assert a[b"metalred\n"].type == pta.LAMBERTIAN
+    assert list(a[b"light\n"].Ke) == [7.5, 7.5, 7.5]
+
+
+def test_mesh_without_mtl_gets_one_default_material():
+    s = host_scene("smallsphere.obj")
+    assert s.num_materials() == 1
+    m = s.get_material(0)
+    assert m.type == pta.LAMBERTIAN and abs(m.Kd[0] - 0.9) < 1e-7 and m.opacity == 1.0 and abs(m.roughness - 0.6) < 1e-7
+    assert not s.get_mesh()[3].any()
+
+
+def test_missing_normals_give_face_normals_and_texcoords_need_a_texture():
+    s = host_scene("cornellbox.obj")
+    pos, nrm, uv, mat = s.get_mesh()
+    p = pos.reshape(-1, 3, 3)
+    n = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    assert np.allclose(nrm.reshape(-1, 3, 3), n[:, None, :], atol=1e-6)
+    assert not uv.any()  # "f a/1 b/1 c/1" but no textured material
+    t = host_scene("textured.obj")
+    assert t.get_mesh()[2].any() and t.get_material(0).textured == 1
+
+
+def test_bad_files(tmp_path):
+    s = pta.Scene(pta.DEVICE_NONE)
+    assert s.load(str(tmp_path / "nope.obj")) is False
+    empty = tmp_path / "empty.obj"
+    empty.write_text("# nothing\nv 0 0 0\n")
+    assert s.load(str(empty)) is False and s.num_triangles() == 0
+    s.create_single_triangle()  # the fallback of src/main.cpp
+    pos, nrm, uv, mat = s.get_mesh()
+    assert pos.tolist() == [[-0.5, -0.5, 0, 0.5, -0.5, 0, 0, 0.5, 0]]
+    assert nrm.reshape(3, 3).tolist() == [[0, 0, 1]] * 3
+    assert uv.tolist() == [[0, 0, 0, 1, 1, 0]]
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\n")
+    assert s.load(str(bad)) is False  # index outside the vertex table: refused, never read out of bounds
+
+
+def test_loader_quirks(tmp_path):
+    """Only the first three vertices of a face are used; a face without a normal index turns
+    normals off for the whole mesh; lines are consumed in 79-byte pieces; usemtl before mtllib
+    still resolves because libraries are read in a first pass."""
+    (tmp_path / "q.mtl").write_text("newmtl a\nKd 1 0 0\nnewmtl glassy\nKd 0 1 0\nRi 2.5\n")
+    obj = tmp_path / "q.obj"
+    obj.write_text("usemtl glassy\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 2\n"
+                   "f 1//1 2//1 3//1 4//1\nusemtl a\nf 1 3 4\nmtllib q.mtl\n")
+    for loader in ("product", "oracle"):
+        if loader == "product":
+            s = pta.Scene(pta.DEVICE_NONE)
+            assert s.load(str(obj))
+            pos, nrm, uv, mat = s.get_mesh()
+            mats = s.materials()
+        else:
+            o = orc.Oracle()
+            assert o.load_obj(str(obj)) == 2
+            pos, nrm, uv, mat = o.get_tris()
+            mats = o.materials()
+        assert pos.shape[0] == 2 and mat.tolist() == [1, 0]
+        assert pos[0].tolist() == [0, 0, 0, 1, 0, 0, 1, 1, 0]
+        assert np.allclose(nrm.reshape(-1, 3), [0, 0, 1])  # geometric normals (second face has no vn)
+        assert mats[1].type == pta.GLASS and mats[1].eta == 1.5  # "glassy" starts with glass; Ri ignored
+    long_line = "v 0.125 0.25 0.5" + " " * 70 + "\n"
+    obj2 = tmp_path / "long.obj"
+    obj2.write_text(long_line + "v 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    s = pta.Scene(pta.DEVICE_NONE)
+    o = orc.Oracle()
+    assert s.load(str(obj2)) and o.load_obj(str(obj2)) == 1
+    assert np.array_equal(s.get_mesh()[0], o.get_tris()[0])
+
+
+def test_host_only_context_refuses_gpu_work():
+    s = host_scene("cornellbox.obj")
+    s.pre_calc(pta.BVH)
+    for call in (lambda: s.set_resolution(8, 8), lambda: s.pathtrace(1), lambda: s.intersect(np.zeros((1, 6), np.float32)),
+                 lambda: s.counters(), lambda: s.synchronize()):
+        with pytest.raises(pta.PtError) as e:
+            call()
+        assert e.value.code == pta.ERR_NOT_READY
