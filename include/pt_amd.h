@@ -61,7 +61,10 @@ enum {
     PT_OPT_MAX_BATCH = 5,     /* most camera samples in flight in one wavefront batch */
     PT_OPT_QUEUE_FACTOR = 6,  /* queue capacity = factor x batch (forked paths), default 4 */
     PT_OPT_LDS_NODES = 7,     /* tree nodes staged in LDS by the trace kernels (0 = none) */
-    PT_OPT_TRAVERSAL = 8      /* 0: division-exact slab tests everywhere; 1: guarded fast slab test */
+    PT_OPT_TRAVERSAL = 8      /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab quotients from
+                                 the per-ray reciprocal plus one exact correction step instead of the division
+                                 sequence (default on); bits 4..7: k of the node phase's early leave rule (default 4,
+                                 0 = none); bit 2: refill a wave only when all its lanes are idle (measurement) */
 };
 
 /* Counter indices for pt_get_counters (all cumulative since pt_reset_counters). */

@@ -49,6 +49,7 @@ struct SceneGpu {
     int n_nodes;
     int lds_nodes;  // nodes [0, lds_nodes) are staged in LDS by the trace kernels
     int n_tris;
+    int planes_ok;  // every box coordinate is 0 or at least 1e-17 in magnitude (reciprocal slab form allowed)
 };
 
 struct CameraGpu {
@@ -74,7 +75,8 @@ struct BatchGpu {
     int n_slots;       // n_pixels * chunk
     int blocks;        // workgroups that share the batch (grid size of every stage)
     int cap_block;     // queue entries owned by one workgroup
-    int slots_block;   // camera samples generated by one workgroup
+    int slots_block;   // most camera samples one workgroup generates
+    int deal_shift;    // rotation of the run -> workgroup assignment per dealing round
 };
 
 enum { TRACE_STACK = 64 };

@@ -74,7 +74,7 @@ struct PtContext {
     // options
     uint64_t seed = 0xcafef00dd15ea5e5ull;
     int max_level = 15;
-    int count_tests = 0, profile = 0, traversal = 0;
+    int count_tests = 0, profile = 0, traversal = 0x41;  // reciprocal-form slab test, leave_k = 4
     size_t max_batch = (size_t)1 << 24;
     int queue_factor = 4;
     int lds_nodes_opt = 256;
@@ -295,6 +295,10 @@ int flatten_and_upload(PtContext* c) {
     s.n_nodes = (int)order.size();
     s.lds_nodes = c->lds_nodes_opt < s.n_nodes ? c->lds_nodes_opt : s.n_nodes;
     s.n_tris = nt;
+    s.planes_ok = 1;
+    for (const HostTree::Node& nd : t.nodes)
+        for (int k = 0; k < 6; k++)
+            if (nd.box[k] != 0.0f && !(std::fabs(nd.box[k]) >= 1e-17f)) s.planes_ok = 0;
     return PT_OK;
 }
 
@@ -376,7 +380,8 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     int nb = (b.n_slots + 2047) / 2048;
     nb = nb < 1 ? 1 : (nb > c->blocks ? c->blocks : nb);
     b.blocks = nb;
-    b.slots_block = (b.n_slots + nb - 1) / nb;
+    b.slots_block = (((b.n_slots + 63) / 64 + nb - 1) / nb) * 64;  // runs of 64 samples dealt in rounds
+    b.deal_shift = nb > 2 ? ((int)(nb * 0.6180339887) | 1) : 0;
     b.cap_block = (int)((c->batch_alloc * (size_t)c->queue_factor) / (size_t)nb);
     const LaunchCfg cfg = cfg_of(c);
     const int levels = c->max_level + 2;  // levels 0 .. maxLevel+1; the last one only resolves misses

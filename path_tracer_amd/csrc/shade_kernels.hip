@@ -212,19 +212,34 @@ __device__ __forceinline__ vec3 texel(const SceneGpu& sc, int tw, int th, int of
 }
 
 // ---- camera rays: Scene::generateRay (src/cs488.h:1825-1839) ----
-// Workgroup b generates the camera samples [b*slots_block, (b+1)*slots_block) into its own region.
+// Camera samples are dealt to the workgroups in runs of 64 consecutive samples (one wave's worth,
+// so a wave's primary rays stay coherent).  Round l deals runs [l*blocks, (l+1)*blocks), and within
+// a round workgroup b takes position (b + l*deal_shift) mod blocks: every workgroup gets one run
+// per round, and the shift keeps a workgroup's runs from lining up in one image column (a plain
+// round-robin does when blocks*64 samples are a whole number of rows).  Every workgroup thus
+// covers the whole image evenly and all of them finish a bounce level at about the same time.
 __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, QueueSet out, float4* __restrict__ sample_rad,
                                                      int* __restrict__ qcount) {
     const int blk = blockIdx.x;
-    const long long first = (long long)blk * b.slots_block;
-    const long long rest = (long long)b.n_slots - first;
-    const int n = rest <= 0 ? 0 : (rest < b.slots_block ? (int)rest : b.slots_block);
-    if (threadIdx.x == 0) qcount[blk] = n;
+    const int runs = (b.n_slots + 63) / 64;  // runs in the batch; only the last one may be short
+    const int full_rounds = runs / b.blocks, rest = runs % b.blocks;
+    const int my_runs = full_rounds + (((blk + (long long)full_rounds * b.deal_shift) % b.blocks) < rest ? 1 : 0);
     const size_t region = (size_t)blk * b.cap_block;
     const vec3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
     const vec3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]), cw = v3(cam.w[0], cam.w[1], cam.w[2]);
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-        const int slot = (int)first + j;
+    int written = 0;
+    if (my_runs > 0) {
+        // the batch's short run, if there is one, is the last run of the last round, hence this
+        // workgroup's last run
+        const int l = my_runs - 1;
+        const int last_run = l * b.blocks + (int)((blk + (long long)l * b.deal_shift) % b.blocks);
+        const int last_len = last_run == runs - 1 ? b.n_slots - last_run * 64 : 64;
+        written = (my_runs - 1) * 64 + last_len;
+    }
+    if (threadIdx.x == 0) qcount[blk] = written;
+    for (int j = threadIdx.x; j < written; j += blockDim.x) {
+        const int l = j >> 6;
+        const int slot = (l * b.blocks + (int)((blk + (long long)l * b.deal_shift) % b.blocks)) * 64 + (j & 63);
         int pixel, sample;
         slot_to_sample(b, slot, pixel, sample);
         const int px = pixel % cam.width, py = pixel / cam.width;

@@ -19,9 +19,13 @@
 // sum separately, and a fused multiply-add here would change low-order bits of t.
 //
 // Launch shape: one 256-lane workgroup per queue region; the region's length is read from device
-// memory (written by the previous stage), so the host never waits for a count.
-// The first `lds_nodes` tree nodes (the top levels; nodes are numbered breadth-first) are copied
-// into LDS by every workgroup that has work.
+// memory (written by the previous stage), so the host never waits for a count.  A wave alternates
+// two phases: all lanes standing on interior nodes walk (slab tests only) until each has reached a
+// leaf or finished, then the lanes standing on leaves test their triangles.  Lanes whose ray is
+// finished take the next rays of the region through an LDS counter (one atomic per refill) as soon
+// as a quarter of the wave is idle.  The first `lds_nodes` tree nodes (the top levels; nodes are numbered breadth-first) are
+// copied into LDS by every workgroup that has work; the first LDS_STACK entries of every lane's
+// traversal stack live in LDS as well.
 #include <float.h>
 
 #include "device_types.h"
@@ -73,13 +77,97 @@ __device__ __forceinline__ void triangle_test(const SceneGpu& sc, int tri, vec3 
     }
 }
 
-template <bool KD, bool COUNT>
+// ---- slab test without the division sequence ---------------------------------------------------
+// SLAB_DIVIDE: the division form above, always.
+// SLAB_RECIP:  every quotient (plane - origin) / direction is formed from the per-ray reciprocal
+//   r = RN(1 / d) as  q0 = RN(a r);  e = RN(fma(-q0, d, a));  q = RN(fma(e, r, q0)).
+//   The residual e is exact and the corrected q equals RN(a / d) for EVERY pair of binary32
+//   significands -- checked exhaustively (2^46 pairs, tools/verify_recip_division.hip) -- hence for
+//   all operands as long as nothing overflows or becomes subnormal.  Rays for which that cannot be
+//   promised from their origin and direction alone (`recip_ok` below) use the division form, so both
+//   settings give bit-identical entry distances and therefore the identical walk.
+enum { SLAB_DIVIDE = 0, SLAB_RECIP = 1 };
+
+__device__ __forceinline__ float div_by_recip(float a, float d, float r) {
+    const float q0 = a * r;
+    const float e = __fmaf_rn(-q0, d, a);
+    return __fmaf_rn(e, r, q0);
+}
+
+__device__ __forceinline__ bool slab_test_recip(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                                vec3 o, vec3 d, vec3 r, float& t_entry) {
+    float tx1 = div_by_recip(lox - o.x, d.x, r.x), ty1 = div_by_recip(loy - o.y, d.y, r.y), tz1 = div_by_recip(loz - o.z, d.z, r.z);
+    float tx2 = div_by_recip(hix - o.x, d.x, r.x), ty2 = div_by_recip(hiy - o.y, d.y, r.y), tz2 = div_by_recip(hiz - o.z, d.z, r.z);
+    if (tx1 > tx2) { float s = tx1; tx1 = tx2; tx2 = s; }
+    if (ty1 > ty2) { float s = ty1; ty1 = ty2; ty2 = s; }
+    if (tz1 > tz2) { float s = tz1; tz1 = tz2; tz2 = s; }
+    float t1 = tx1; if (t1 < ty1) t1 = ty1; if (t1 < tz1) t1 = tz1;
+    float t2 = tx2; if (t2 > ty2) t2 = ty2; if (t2 > tz2) t2 = tz2;
+    t_entry = t1;
+    if (t1 > t2) return false;
+    if ((t1 < 0.0f) && (t2 < 0.0f)) return false;
+    return true;
+}
+
+// May the reciprocal form be used for this ray?  Needs, per axis: a finite direction component
+// with 1e-10 <= |d| <= 1e10 (so r and every quotient stay normal), an origin coordinate that is 0
+// or at least 1e-17 in magnitude (with the same property of the box planes, checked on the host,
+// a non-zero plane - origin is then at least 1e-25 and its quotient and residual stay normal), and
+// |plane - origin| < 1e15 for every plane inside the root box.
+__device__ __forceinline__ bool recip_ok(vec3 o, vec3 d, vec3 rlo, vec3 rhi) {
+    const float dmax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float dmin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float reach = fmaxf(fmaxf(fmaxf(fabsf(rlo.x - o.x), fabsf(rhi.x - o.x)), fmaxf(fabsf(rlo.y - o.y), fabsf(rhi.y - o.y))),
+                              fmaxf(fabsf(rlo.z - o.z), fabsf(rhi.z - o.z)));
+    const bool ox = o.x == 0.0f || fabsf(o.x) >= 1e-17f, oy = o.y == 0.0f || fabsf(o.y) >= 1e-17f, oz = o.z == 0.0f || fabsf(o.z) >= 1e-17f;
+    return (dmax <= 1e10f) && (dmin >= 1e-10f) && (reach < 1e15f) && ox && oy && oz;  // NaNs fail the comparisons
+}
+
+// What one visit of an interior node decides.
+struct NodeStep {
+    int next;          // child to enter now (valid if descend)
+    int deferred;      // child to push (valid if push)
+    float deferred_t;  // its entry distance (kd-tree only)
+    bool descend, push;
+};
+
+// The reference's decisions for one interior node (src/cs488.h:1684-1701, 1357-1375).
+template <bool RECIP>
+__device__ __forceinline__ void node_step(const float4& q0, const float4& q1, const float4& q2, const float4& q3,
+                                          vec3 o, vec3 d, vec3 r, float best_t, NodeStep& st) {
+    float tl, tr;
+    bool hl, hr;
+    if (RECIP) {
+        hl = slab_test_recip(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, r, tl);
+        hr = slab_test_recip(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, r, tr);
+    } else {
+        hl = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tl);
+        hr = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tr);
+    }
+    hl = hl && (tl < best_t);
+    hr = hr && (tr < best_t);
+    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+    st.push = hl && hr;
+    st.descend = hl || hr;
+    const bool left_first = st.push ? (tl < tr) : hl;
+    st.next = left_first ? left : right;
+    st.deferred = left_first ? right : left;
+    st.deferred_t = left_first ? tr : tl;
+}
+
+// The first LDS_STACK entries of a lane's traversal stack live in LDS (entry e of lane t at
+// [e * 256 + t]: consecutive lanes on consecutive banks), deeper ones in the lane's scratch array.
+enum { LDS_STACK = 12 };
+
+template <bool KD, bool COUNT, int SLAB, bool DYNAMIC>
 __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
                                                     const float4* __restrict__ ray_d, float4* __restrict__ hit,
                                                     const int* __restrict__ n_ptr, int n_fixed, int cap_block,
-                                                    unsigned long long* __restrict__ block_stats) {
+                                                    unsigned long long* __restrict__ block_stats, int leave_k) {
     extern __shared__ float4 lds_nodes[];
-    __shared__ __attribute__((aligned(16))) unsigned int s_stat[4];  // 16 bytes: keeps the dynamic region 16-byte aligned
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[4];  // hits, slab tests, triangle tests, next ray
+    __shared__ __attribute__((aligned(16))) int s_stack[LDS_STACK * 256];
+    __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LDS_STACK * 256 : 4];
     const int blk = blockIdx.x;
     int n;
     if (n_ptr) {
@@ -94,37 +182,91 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
 
     const int staged = sc.lds_nodes;
     for (int k = threadIdx.x; k < staged * 4; k += blockDim.x) lds_nodes[k] = sc.nodes[k];
-    if (threadIdx.x < 3) s_stat[threadIdx.x] = 0;
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
     const vec3 rlo = v3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]);
     const vec3 rhi = v3(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2]);
     unsigned int n_box = 0, n_tri = 0, n_hit = 0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
 
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-        const size_t i = region + j;
-        const float4 ro = ray_o[i], rd = ray_d[i];
-        const vec3 o = v3(ro.x, ro.y, ro.z), d = v3(rd.x, rd.y, rd.z);
-        Best best;
-        best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+    // per-lane state of the ray in progress
+    vec3 o = v3(0.0f), d = v3(0.0f), inv = v3(0.0f);
+    Best best;
+    best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+    int deep[TRACE_STACK - LDS_STACK];
+    float deep_t[KD ? TRACE_STACK - LDS_STACK : 1];
+    int sp = 0, cur = 0;
+    size_t slot = 0;
+    bool have = false, fast_ok = false;
+    bool drained = false;  // wave-uniform: the region has no unassigned ray left
+    const int refill_min = DYNAMIC ? 16 : 64;
 
-        int stack[TRACE_STACK];
-        float stack_t[KD ? TRACE_STACK : 1];
-        int sp = 0;
-        float t_root;
-        if (COUNT) n_box++;
-        bool walking = slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
-        int cur = sc.root_ref;
-        while (walking) {
-            if (cur < 0) {
-                const int off = ~cur;
-                const int cnt = sc.refs[off];
-                for (int k = 1; k <= cnt; k++) {
-                    if (COUNT) n_tri++;
-                    triangle_test(sc, sc.refs[off + k], o, d, best);
-                }
-                walking = false;
+    // Takes the next deferred child; when none is left the ray is finished and its record written.
+    auto pop_or_finish = [&]() {
+        while (sp > 0) {
+            sp--;
+            int ref;
+            float t_ref = 0.0f;
+            if (sp < LDS_STACK) {
+                ref = s_stack[sp * 256 + tid];
+                if (KD) t_ref = s_stack_t[sp * 256 + tid];
             } else {
+                ref = deep[sp - LDS_STACK];
+                if (KD) t_ref = deep_t[sp - LDS_STACK];
+            }
+            if (KD && !(t_ref < best.t)) continue;
+            cur = ref;
+            return;
+        }
+        if (best.tri >= 0) n_hit++;
+        hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.beta, best.gamma);
+        have = false;
+    };
+
+    while (true) {
+        // ---- idle lanes take the next rays of the region, once enough of them are idle ----
+        const unsigned long long idle = __ballot(!have);
+        const int n_idle = __popcll(idle);
+        if (n_idle == 64 && drained) break;
+        if (!drained && n_idle >= refill_min) {
+            int base = 0;
+            if (lane == 0) base = (int)atomicAdd(&s_stat[3], (unsigned int)n_idle);
+            base = __shfl(base, 0);
+            drained = base + n_idle >= n;
+            const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
+            if (!have && j < n) {
+                slot = region + j;
+                const float4 ro = ray_o[slot], rd = ray_d[slot];
+                o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
+                best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+                sp = 0;
+                if (SLAB == SLAB_RECIP) {
+                    fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
+                    if (fast_ok) inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                }
+                float t_root;
+                if (COUNT) n_box++;
+                const bool in_root = (SLAB == SLAB_RECIP && fast_ok) ? slab_test_recip(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, inv, t_root)
+                                                                     : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
+                if (in_root) {  // src/cs488.h:1438, 1405
+                    cur = sc.root_ref;
+                    have = true;
+                } else {
+                    hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
+                }
+            }
+        }
+
+        // ---- phase A: every lane standing on an interior node walks until it reaches a leaf ----
+        while (true) {
+            // leave the phase when nobody stands on a node, or (leave_k > 0) when the lanes still
+            // walking are fewer than 1/leave_k of the lanes already waiting at a leaf
+            const int walking = __popcll(__ballot(have && cur >= 0));
+            if (walking == 0) break;
+            if (leave_k > 0 && walking * leave_k < __popcll(__ballot(have && cur < 0))) break;
+            if (have && cur >= 0) {
                 float4 q0, q1, q2, q3;
                 if (cur < staged) {
                     q0 = lds_nodes[4 * cur]; q1 = lds_nodes[4 * cur + 1]; q2 = lds_nodes[4 * cur + 2]; q3 = lds_nodes[4 * cur + 3];
@@ -132,40 +274,34 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                     const float4* np = sc.nodes + 4 * (size_t)cur;
                     q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
                 }
-                float tl, tr;
                 if (COUNT) n_box += 2;
-                bool hl = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tl);
-                bool hr = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tr);
-                hl = hl && (tl < best.t);
-                hr = hr && (tr < best.t);
-                const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-                if (hl && hr) {
-                    const bool left_first = tl < tr;
-                    stack[sp] = left_first ? right : left;
-                    if (KD) stack_t[sp] = left_first ? tr : tl;
+                NodeStep st;
+                if (SLAB == SLAB_RECIP && fast_ok) node_step<true>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                else node_step<false>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                if (st.push) {
+                    if (sp < LDS_STACK) {
+                        s_stack[sp * 256 + tid] = st.deferred;
+                        if (KD) s_stack_t[sp * 256 + tid] = st.deferred_t;
+                    } else {
+                        deep[sp - LDS_STACK] = st.deferred;
+                        if (KD) deep_t[sp - LDS_STACK] = st.deferred_t;
+                    }
                     sp++;
-                    cur = left_first ? left : right;
-                    continue;
-                } else if (hl) {
-                    cur = left;
-                    continue;
-                } else if (hr) {
-                    cur = right;
-                    continue;
                 }
-                walking = false;
-            }
-            // take the next deferred child
-            while (sp > 0) {
-                sp--;
-                if (KD && !(stack_t[sp] < best.t)) continue;
-                cur = stack[sp];
-                walking = true;
-                break;
+                if (st.descend) cur = st.next; else pop_or_finish();
             }
         }
-        if (best.tri >= 0) n_hit++;
-        hit[i] = make_float4(__int_as_float(best.tri), best.t, best.beta, best.gamma);
+
+        // ---- phase B: lanes standing on a leaf test its triangles in stored order ----
+        if (have && cur < 0) {
+            const int off = ~cur;
+            const int cnt = sc.refs[off];
+            for (int k = 1; k <= cnt; k++) {
+                if (COUNT) n_tri++;
+                triangle_test(sc, sc.refs[off + k], o, d, best);
+            }
+            pop_or_finish();
+        }
     }
 
     // statistics: wave sums -> LDS -> this workgroup's own slots (no global atomics)
@@ -174,7 +310,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
         tot_hit += __shfl_down(tot_hit, off);
         if (COUNT) { tot_box += __shfl_down(tot_box, off); tot_tri += __shfl_down(tot_tri, off); }
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         atomicAdd(&s_stat[0], tot_hit);
         if (COUNT) { atomicAdd(&s_stat[1], tot_box); atomicAdd(&s_stat[2], tot_tri); }
     }
@@ -205,20 +341,45 @@ __global__ void unpack_hits_kernel(const float4* __restrict__ hit, int n, int* t
     }
 }
 
+template <bool KD, bool COUNT, int SLAB, bool DYNAMIC>
+void launch_variant(const LaunchCfg& cfg, const SceneGpu& scene, const float4* ray_o, const float4* ray_d, float4* hit,
+                    const int* n_rays, int n_fixed, int grid_blocks, int cap_block, unsigned long long* block_stats, int leave_k) {
+    const size_t lds = (size_t)scene.lds_nodes * 64;
+    hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene, ray_o,
+                       ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
+}
+
+template <bool KD, bool COUNT>
+void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const float4* ray_o, const float4* ray_d,
+                    float4* hit, const int* n_rays, int n_fixed, int grid_blocks, int cap_block,
+                    unsigned long long* block_stats) {
+    // mode: bit 0 = reciprocal-form slab test, bit 2 = refill only when the whole wave is idle
+    // (measurement), bits 4..7 = leave_k of the node phase (0 = run it until nobody walks)
+    const bool recip = (mode & 1) != 0;
+    const bool dynamic = (mode & 4) == 0;
+    const int leave_k = (mode >> 4) & 15;
+#define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats, leave_k
+    if (dynamic) {
+        if (recip) launch_variant<KD, COUNT, SLAB_RECIP, true>(PT_ARGS);
+        else launch_variant<KD, COUNT, SLAB_DIVIDE, true>(PT_ARGS);
+    } else {
+        if (recip) launch_variant<KD, COUNT, SLAB_RECIP, false>(PT_ARGS);
+        else launch_variant<KD, COUNT, SLAB_DIVIDE, false>(PT_ARGS);
+    }
+#undef PT_ARGS
+}
+
 }  // namespace
 
-hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int count_tests, int fast_slab,
+hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int count_tests, int mode,
                         const float4* ray_o, const float4* ray_d, float4* hit, const int* n_rays, int n_fixed,
                         int grid_blocks, int cap_block, unsigned long long* block_stats) {
-    (void)fast_slab;
-    const size_t lds = (size_t)scene.lds_nodes * 64;
-    dim3 grid(grid_blocks), block(256);
     if (kd) {
-        if (count_tests) hipLaunchKernelGGL((trace_kernel<true, true>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats);
-        else hipLaunchKernelGGL((trace_kernel<true, false>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats);
+        if (count_tests) launch_by_mode<true, true>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats);
+        else launch_by_mode<true, false>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats);
     } else {
-        if (count_tests) hipLaunchKernelGGL((trace_kernel<false, true>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), grid, block, lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats);
+        if (count_tests) launch_by_mode<false, true>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats);
+        else launch_by_mode<false, false>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats);
     }
     return hipGetLastError();
 }

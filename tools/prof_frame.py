@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Small workload for rocprofv3 passes: a few progressive frames of one scene, no PyTorch.
+usage: prof_frame.py [scene.obj] [resolution] [frames] [accel bvh|kd] [traversal mode]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+    sys.path.insert(0, p)
+import path_tracer_amd as pta  # noqa: E402
+from common import scene_path  # noqa: E402
+
+obj = sys.argv[1] if len(sys.argv) > 1 else "cornellbox.obj"
+res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+accel = pta.KD if (len(sys.argv) > 4 and sys.argv[4] == "kd") else pta.BVH
+s = pta.Scene(0)
+assert s.load(scene_path(obj))
+if obj.startswith("teapot"):
+    s.load_env(scene_path("probe_64.hdr"))
+s.pre_calc(accel)
+if len(sys.argv) > 5:
+    s.set_option(pta.OPT_TRAVERSAL, int(sys.argv[5], 0))
+s.set_resolution(res, res)
+for _ in range(frames):
+    s.pathtrace(10)
+s.synchronize()
+c = s.counters()
+print("rays", c[0], "samples", c[3])
