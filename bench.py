@@ -35,7 +35,43 @@ WORKLOADS = {
     "cornellbox-alpha": ("cornellbox-alpha.obj", True),
     "cornellball-glass": ("cornellball-glass.obj", False),
     "teapot": ("teapot.obj", True),
+    # procedural stand-in for the undistributed sponza.obj (tools/make_sponza.py), probe-lit
+    "sponza": (None, True),
 }
+# per-workload defaults (width, height, spp per frame and GPU); the command line overrides them
+DEFAULT_SHAPE = {"sponza": (3840, 2160, 4)}
+
+
+def sponza_path():
+    """Generates the stand-in courtyard once (seeded, ~210 k triangles) and returns its .obj path."""
+    from make_sponza import build, write
+    folder = os.path.join(ROOT, "gpurun_out", "sponza")
+    path = os.path.join(folder, "sponza_standin.obj")
+    if not os.path.exists(path):
+        tmp = os.path.join(ROOT, "gpurun_out", "sponza.%d.tmp" % os.getpid())
+        os.makedirs(tmp, exist_ok=True)
+        write(build(seed=7, detail=1.0), os.path.join(tmp, "sponza_standin.obj"))
+        try:
+            os.replace(tmp, folder)
+        except OSError:  # another rank was first
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+    return path
+
+
+def workload_obj(args):
+    from common import scene_path
+    if args.obj:
+        return args.obj
+    obj = WORKLOADS[args.workload][0]
+    return sponza_path() if obj is None else scene_path(obj)
+
+
+def workload_camera(args):
+    if args.workload == "sponza" and not args.obj:
+        from make_sponza import CAMERA
+        return CAMERA
+    return None
 
 
 def bytes_per_ray(n_box, n_tri, hit_frac, textured=False):
@@ -46,19 +82,19 @@ def bytes_per_ray(n_box, n_tri, hit_frac, textured=False):
 
 
 def make_scene(pta, args, device, accel):
-    from common import scene_path
-    obj, needs_probe = WORKLOADS[args.workload]
+    needs_probe = WORKLOADS[args.workload][1]
     s = pta.Scene(device)
+    path = workload_obj(args)
+    if not s.load(path):
+        raise SystemExit("cannot load %s" % path)
     if args.obj:
-        if not s.load(args.obj):
-            raise SystemExit("cannot load %s" % args.obj)
         if args.hdr:
             s.load_env(args.hdr)
-    else:
-        if not s.load(scene_path(obj)):
-            raise SystemExit("cannot load %s" % obj)
-        if needs_probe:
-            s.load_env(probe_path(args))
+    elif needs_probe:
+        s.load_env(probe_path(args))
+    cam = workload_camera(args)
+    if cam:
+        s.set_camera(**cam)
     s.pre_calc(accel)
     s.set_resolution(args.width, args.height)
     return s
@@ -80,15 +116,30 @@ def cpu_baseline(args):
     """The CPU restatement of the reference's multithreaded loop (column strips, one thread per
     strip), timed on this host on a bounded sample of the same workload."""
     import orc
-    from common import load_oracle_scene, read_hdr_independent
-    obj, needs_probe = WORKLOADS[args.workload]
+    from PIL import Image
+    from common import read_hdr_independent
+    needs_probe = WORKLOADS[args.workload][1]
     cores = min(16, os.cpu_count() or 1)
-    o = load_oracle_scene(obj, orc.BVH if args.accel == "bvh" else orc.KD)
-    if needs_probe:
+    o = orc.Oracle()
+    if o.load_obj(workload_obj(args)) <= 0:
+        raise SystemExit("oracle cannot load the workload")
+    for i, m in enumerate(o.materials()):
+        if m.textured:
+            o.set_texture(i, np.asarray(Image.open(m.tex_file.decode()).convert("RGB"), np.uint8))
+    if needs_probe and not args.obj:
         o.set_env(read_hdr_independent(probe_path(args)))
-    o.reset(args.width, args.height)
+    cam = workload_camera(args)
+    if cam:
+        o.set_camera(**cam)
+    o.build(orc.BVH if args.accel == "bvh" else orc.KD)
+    # bounded sample: the same view and spp on an image shrunk until one frame is <= 12 M samples
+    w, h, shrink = args.width, args.height, 1
+    while (w // shrink) * (h // shrink) * args.spp > 12_000_000:
+        shrink *= 2
+    w, h = w // shrink, h // shrink
+    o.reset(w, h)
     o.render(spp=1, frames=1, threads=cores)  # warm-up
-    o.reset(args.width, args.height)
+    o.reset(w, h)
     frames, t0, rays = 0, time.time(), 0
     while True:
         _, _, cnt = o.render(spp=args.spp, frames=1, threads=cores)
@@ -99,9 +150,9 @@ def cpu_baseline(args):
             break
     return {
         "value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "spp_per_s": frames * args.spp / dt,
-        "sample": "%d frame(s) of the same %dx%d x %d spp workload, %d threads over column strips" % (
-            frames, args.width, args.height, args.spp, cores),
+        "spp_per_s": frames * args.spp / dt * (w * h) / float(args.width * args.height),
+        "sample": "%d frame(s) of the same view at %dx%d (1/%d of the workload's resolution per axis) x %d spp, %d threads over "
+                  "column strips; spp_per_s is scaled to the workload's pixel count" % (frames, w, h, shrink, args.spp, cores),
     }
 
 
@@ -114,12 +165,18 @@ def main():
     ap.add_argument("--obj", default=None, help="render this .obj instead of a named workload")
     ap.add_argument("--hdr", default=None)
     ap.add_argument("--accel", default="bvh", choices=["bvh", "kd"])
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=10, help="samples per pixel per frame and per GPU")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel per frame and per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kd", action="store_true", help="skip the short kd-tree comparison run")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo only rehearses the multi-process path on a box with one GPU")
     args = ap.parse_args()
+    dw, dh, dspp = DEFAULT_SHAPE.get(args.workload, (1024, 1024, 10))
+    args.width = args.width or dw
+    args.height = args.height or dh
+    args.spp = args.spp or dspp
 
     import torch
     import torch.distributed as dist
@@ -132,10 +189,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     accel = pta.BVH if args.accel == "bvh" else pta.KD
     scene = make_scene(pta, args, local_rank, accel)
@@ -194,10 +255,11 @@ def main():
     max_queue = c[pta.CNT_MAX_QUEUE]
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+        r = torch.tensor([rays_local], dtype=torch.float64, device=dev)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rays_total = float(r.item())
     else:
@@ -212,10 +274,12 @@ def main():
             "metric": "Mrays/s", "value": rays_total / elapsed * 1e-6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if WORKLOADS[args.workload][1] else "reference scene file",
+            "vs_baseline": None, "dtype": "f32", "data": ("synthetic scene + synthetic probe" if args.workload == "sponza" else
+                     "reference scene file + synthetic probe" if WORKLOADS[args.workload][1] else "reference scene file"),
             "config": {
                 "workload": "%s %dx%d, %d spp/frame/GPU, SAH %s, progressive" % (
-                    args.obj or WORKLOADS[args.workload][0], args.width, args.height, args.spp, args.accel.upper()),
+                    args.obj or WORKLOADS[args.workload][0] or "sponza stand-in (tools/make_sponza.py)", args.width, args.height,
+                    args.spp, args.accel.upper()),
                 "parallelism": "sample-split x%d + RCCL reduce of the accumulation buffer" % world if world > 1 else "single GPU",
             },
             "spp_per_s": args.spp * world * args.steps / elapsed,

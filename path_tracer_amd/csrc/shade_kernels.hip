@@ -462,28 +462,23 @@ __global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float
     if (dropped) atomicAdd(&totals[DC_NAN], (unsigned long long)dropped);
 }
 
-// Per level: total queue population of the batch = closest-hit queries of that level.
-__global__ __launch_bounds__(256) void tally_kernel(const int* __restrict__ qcount, int levels, int blocks,
+// Per level (one workgroup each): total queue population of the batch = closest-hit queries of
+// that level; the sum over levels goes to DC_RAYS, the largest level to DC_MAXQ.
+__global__ __launch_bounds__(256) void tally_kernel(const int* __restrict__ qcount, int blocks,
                                                     unsigned long long* __restrict__ totals) {
     __shared__ unsigned long long s_sum[256];
-    unsigned long long rays = 0, peak = 0;
-    for (int level = 0; level < levels; level++) {
-        unsigned long long part = 0;
-        for (int k = threadIdx.x; k < blocks; k += blockDim.x) part += (unsigned long long)qcount[(size_t)level * blocks + k];
-        s_sum[threadIdx.x] = part;
+    const int level = blockIdx.x;
+    unsigned long long part = 0;
+    for (int k = threadIdx.x; k < blocks; k += blockDim.x) part += (unsigned long long)qcount[(size_t)level * blocks + k];
+    s_sum[threadIdx.x] = part;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
-            __syncthreads();
-        }
-        const unsigned long long total = s_sum[0];
-        __syncthreads();
-        rays += total;
-        peak = total > peak ? total : peak;
     }
-    if (threadIdx.x == 0) {
-        totals[DC_RAYS] += rays;
-        if (peak > totals[DC_MAXQ]) totals[DC_MAXQ] = peak;
+    if (threadIdx.x == 0 && s_sum[0] != 0) {
+        atomicAdd(&totals[DC_RAYS], s_sum[0]);
+        atomicMax(&totals[DC_MAXQ], s_sum[0]);
     }
 }
 
@@ -522,7 +517,7 @@ hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const 
 }
 
 hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, unsigned long long* totals) {
-    hipLaunchKernelGGL(tally_kernel, dim3(1), dim3(256), 0, cfg.stream, qcount, levels, blocks, totals);
+    hipLaunchKernelGGL(tally_kernel, dim3(levels), dim3(256), 0, cfg.stream, qcount, blocks, totals);
     return hipGetLastError();
 }
 

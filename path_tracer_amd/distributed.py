@@ -33,7 +33,13 @@ class FrameReducer:
 
     def reduce(self, spp_frame):
         if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
-            self.dist.reduce(self.delta, dst=self.root, op=self.dist.ReduceOp.SUM, group=self.group)
+            if self.delta.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # rehearsal path (gloo reduces host tensors only): stage through host memory
+                host = self.delta.cpu()
+                self.dist.reduce(host, dst=self.root, op=self.dist.ReduceOp.SUM, group=self.group)
+                self.delta.copy_(host)
+            else:
+                self.dist.reduce(self.delta, dst=self.root, op=self.dist.ReduceOp.SUM, group=self.group)
         self.total_samples += spp_frame
         if self.rank == self.root:
             self.master.add_(self.delta)
