@@ -74,6 +74,20 @@ def workload_camera(args):
     return None
 
 
+def measured_traffic(args, world):
+    """HBM bytes per trace_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of the same workload, read side doubled as gfx950 needs);
+    counters cannot be read inside this process, so the number is only attached to the workload
+    those passes ran (the default one) and is null otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    is_default = (args.workload == "cornellbox" and not args.obj and args.accel == "bvh" and
+                  (args.width, args.height, args.spp) == (1024, 1024, 10) and world == 1)
+    if not is_default or not os.path.exists(path):
+        return None, None
+    k = json.load(open(path))["kernels"].get("trace_kernel")
+    return (k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json") if k else (None, None)
+
+
 def bytes_per_ray(n_box, n_tri, hit_frac, textured=False):
     """Algorithmic bytes one closest-hit query moves: 24 B per slab test (6 floats), 36 B per
     triangle test (9 floats), 48 B of normals + material id for a winning hit, 160 B of wavefront
@@ -269,6 +283,7 @@ def main():
     if rank == 0:
         b_ray = bytes_per_ray(n_box, n_tri, hit_frac)
         trace_s = ms[pta.TIMER_TRACE] * 1e-3
+        traffic, traffic_source = measured_traffic(args, world)
         achieved = rays_local * b_ray / trace_s * 1e-9 if trace_s > 0 else 0.0
         out = {
             "metric": "Mrays/s", "value": rays_total / elapsed * 1e-6, "unit": "Mrays/s",
@@ -286,7 +301,9 @@ def main():
             "rays_per_sample": rays_local / (float(n_pix) * args.spp * args.steps),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": rays_local * b_ray / max(launches[pta.TIMER_TRACE], 1),
                 "kernel": "trace_kernel (closest hit)", "bytes_per_ray": b_ray,
                 "box_tests_per_ray": n_box, "tri_tests_per_ray": n_tri, "hit_fraction": hit_frac,
                 "launches": launches[pta.TIMER_TRACE], "avg_launch_ms": ms[pta.TIMER_TRACE] / max(launches[pta.TIMER_TRACE], 1),

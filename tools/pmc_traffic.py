@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into HBM traffic per kernel launch.
+
+FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts a wide coalesced read
+stream at half its bytes (128-byte requests tallied as 64), so the read side is doubled;
+WRITE_SIZE is exact for 16-byte-per-lane stores.  usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json> [note]
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def collect(d, counter):
+    tot, n = defaultdict(float), defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"]
+            k = "trace_kernel" if "trace_kernel" in k else "shade_kernel" if "shade_kernel" in k else \
+                "raygen_kernel" if "raygen" in k else "accumulate_kernel" if "accumulate" in k else None
+            if k:
+                tot[k] += float(r["Counter_Value"])
+                n[k].add(r["Dispatch_Id"])
+    return tot, {k: len(v) for k, v in n.items()}
+
+
+fetch, nf = collect(sys.argv[1], "FETCH_SIZE")
+write, nw = collect(sys.argv[2], "WRITE_SIZE")
+out = {"note": sys.argv[4] if len(sys.argv) > 4 else "", "kernels": {}}
+for k in sorted(fetch):
+    rd = fetch[k] * 1024 * 2.0   # KiB -> bytes, gfx950 half-count correction for wide coalesced reads
+    wr = write.get(k, 0.0) * 1024
+    launches = nf[k]
+    out["kernels"][k] = {"launches": launches, "fetch_bytes_corrected": rd, "write_bytes": wr,
+                         "hbm_bytes_per_launch": (rd + wr) / max(launches, 1)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
