@@ -1,0 +1,145 @@
+"""GPU tests of the trace-kernel settings (all must give bit-identical hits), the exactness of the
+reciprocal-form division they rely on, the procedural courtyard scene, and the CS488 command line."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+import path_tracer_amd as pta
+from common import ROOT, load_gpu_scene, load_oracle_scene, ray_batch, scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("obj,accel", [("cornellbox.obj", pta.BVH), ("cornellball-glass.obj", pta.KD), ("teapot.obj", pta.BVH)])
+def test_every_traversal_setting_gives_the_oracle_hits(gpu_device, obj, accel):
+    o = load_oracle_scene(obj, accel, textures=False)
+    rays = ray_batch(o.get_tris()[0], n_random=6000, n_vertex=600, seed=11)
+    # add rays outside the range the reciprocal form is trusted for: they must take the division form
+    extra = np.array([[0, 0, 1.5, 0, 0, -1], [0, 0, 1.5, 1e-12, 0.3, -1], [1e-20, 0, 1.5, 0.1, 0.2, -1],
+                      [0, 0, 1.5, 1e12, 3.0, -1e12], [0.1, 0.1, 2e15, 0.01, 0.02, -1]], np.float32)
+    rays = np.concatenate([rays, extra])
+    ref = o.trace(rays)
+    s = load_gpu_scene(obj, accel)
+    for mode in (0x00, 0x01, 0x04, 0x05, 0x21, 0x41, 0xF1):
+        s.set_option(pta.OPT_TRAVERSAL, mode)
+        got = s.intersect(rays)
+        assert np.array_equal(got["tri"], ref["tri"]), hex(mode)
+        assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32)), hex(mode)
+        assert np.array_equal(got["bary"].view(np.uint32), ref["bary"].view(np.uint32)), hex(mode)
+    assert s.get_option(pta.OPT_TRAVERSAL) == 0xF1
+
+
+def test_traversal_settings_give_the_same_image(gpu_device):
+    imgs = []
+    for mode in (0x00, 0x41):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        s.set_option(pta.OPT_TRAVERSAL, mode)
+        s.set_resolution(96, 72)
+        s.pathtrace(8)
+        imgs.append(s.accumulation_buffer())
+    assert np.array_equal(imgs[0], imgs[1])  # same hits, same random numbers, no forks in this scene
+
+
+def test_reciprocal_division_is_exact_on_a_slice(gpu_device):
+    """The exhaustive run (all 2^46 significand pairs, no mismatch) is recorded in
+    profiles/r01_verify_recip_division.log; here 2^37 pairs from both ends and the middle."""
+    exe = os.path.join(ROOT, "tools", "verify_recip")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    for first in ("0", "511", "1022"):
+        out = subprocess.run([exe, first, "2"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert re.search(r"TOTAL 137438953472 pairs, 0 mismatches", out.stdout), out.stdout
+    bad = subprocess.run([exe, "300", "1", "1"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1  # the uncorrected product is caught by the same checker
+
+
+def test_courtyard_stand_in_scene(gpu_device, tmp_path):
+    """Small version of the sponza stand-in: every material kind, texture, probe; loader and hits
+    against the oracle, image against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_sponza import CAMERA, build, write
+    from PIL import Image
+    obj = str(tmp_path / "court.obj")
+    n = write(build(seed=7, detail=0.2), obj)
+    assert 5000 < n < 20000
+    o = orc.Oracle()
+    assert o.load_obj(obj) == n
+    for i, m in enumerate(o.materials()):
+        if m.textured:
+            o.set_texture(i, np.asarray(Image.open(m.tex_file.decode()).convert("RGB"), np.uint8))
+    from common import read_hdr_independent
+    o.set_env(read_hdr_independent(scene_path("probe_64.hdr")))
+    o.set_camera(**CAMERA)
+    o.build(orc.BVH)
+    s = pta.Scene(gpu_device)
+    assert s.load(obj) and s.num_triangles() == n
+    types = sorted(m.type for m in s.materials())
+    assert types.count(pta.METAL) == 1 and types.count(pta.GLASS) == 1
+    s.load_env(scene_path("probe_64.hdr"))
+    s.set_camera(**CAMERA)
+    s.pre_calc(pta.BVH)
+    W, H = 96, 54
+    s.set_resolution(W, H)
+    rays = s.camera_rays()
+    ref, got = o.trace(rays), s.intersect(rays)
+    assert np.array_equal(ref["tri"], got["tri"]) and np.array_equal(ref["t"].view(np.uint32), got["t"].view(np.uint32))
+    for _ in range(4):
+        s.pathtrace(16)
+    g = s.frame_buffer()
+    o.reset(W, H)
+    o.render(spp=16, frames=4, threads=8)
+    a = o.image()
+    o.reset(W, H)
+    o.render(spp=16, frames=4, threads=8, state=0x5DEECE66D | 1)
+    b = o.image()
+    floor = float(np.sqrt(np.mean((a - b) ** 2)))
+    assert float(np.sqrt(np.mean((g - a) ** 2))) <= 1.25 * floor
+    assert abs(g.mean() - a.mean()) <= 0.03 * a.mean()
+
+
+def run_cli(*args):
+    exe = os.path.join(ROOT, "path_tracer_amd", "CS488")
+    return subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=120)
+
+
+def test_cli_stdout_protocol(gpu_device, tmp_path):
+    obj = scene_path("cornellbox.obj")
+    out_png = str(tmp_path / "frame.png")
+    r = run_cli(obj, "--frames", "3", "--width", "64", "--height", "48", "--out", out_png)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == 'Loading "%s"...' % obj
+    assert lines[1] == 'Loaded "%s" with 36 triangles.' % obj
+    assert lines[2] == "Building KdTree..." and lines[3] == "Done."   # kd-tree is the reference's default
+    body = lines[4:10]
+    assert [body[0], body[2], body[4]] == ["10", "20", "30"]            # total samples, then seconds, per frame
+    for sec in (body[1], body[3], body[5]):
+        assert float(sec) > 0
+    assert lines[10] == 'Saved "%s".' % out_png
+    from PIL import Image
+    img = np.asarray(Image.open(out_png))
+    assert img.shape == (48, 64, 3) and img.max() == 255 and img[0].max() < 5   # light saturates; top border is black
+    r = run_cli(obj, scene_path("probe_64.hdr"), "--accel", "bvh", "--frames", "1", "--spp", "2", "--width", "32", "--height", "24",
+                "--no-progressive", "--stats")
+    assert r.returncode == 0
+    assert 'Loaded "%s".' % scene_path("probe_64.hdr") in r.stdout and "Building BVH..." in r.stdout
+    assert r.stdout.splitlines()[-2] == "2" and "Mrays/s" in r.stderr
+
+
+def test_cli_fallbacks(gpu_device, tmp_path):
+    r = run_cli("--frames", "1", "--width", "16", "--height", "12")
+    assert r.returncode == 0
+    assert r.stdout.startswith("Specify .obj file in the command line arguments. Example: CS488.exe cornellbox.obj\n"
+                               "Making a single triangle instead.\nBuilding KdTree...\nDone.\n10\n")
+    missing = str(tmp_path / "none.obj")
+    r = run_cli(missing, "--frames", "1", "--width", "16", "--height", "12")
+    assert r.returncode == 0
+    assert r.stdout.startswith('Loading "%s"...\nCannot open "%s" for reading\nInvalid .obj file.\nMaking a single triangle instead.\n'
+                               % (missing, missing))
+    r = run_cli(scene_path("cornellbox.obj"), "--accel", "octree")
+    assert r.returncode == 2
