@@ -6,10 +6,20 @@
 // visit (src/cs488.h:1684-1685, 1357-1358).
 //     q0 = (Lmin.x, Lmin.y, Lmin.z, Lmax.x)   q1 = (Lmax.y, Lmax.z, Rmin.x, Rmin.y)
 //     q2 = (Rmin.z, Rmax.x, Rmax.y, Rmax.z)   q3 = bit patterns of (left, right, 0, 0)
-// A child reference >= 0 is the index of another interior node; a reference < 0 is a leaf and
-// ~reference is the offset of its list in `refs`: refs[off] = n, refs[off+1..off+n] = triangle
-// indices in the reference's leaf order.  Interior nodes are numbered breadth-first, so the
-// first K nodes are the top of the tree (the part staged in LDS).
+// A child reference >= 0 is the index of another interior node; a reference < 0 is a leaf (see
+// the intersection records below).  Interior nodes are numbered breadth-first, so the first K
+// nodes are the top of the tree (the part staged in LDS).
+//
+// Intersection records (`isect`, four float4 = 64 bytes each): everything the triangle test needs
+// that does not depend on the ray, computed on the host with the reference's own operations
+// (src/cs488.h:651-652, 656 with src/linalg.h:500), so the values are bit for bit what the test
+// would compute itself:
+//     r0 = (p0.xyz, triangle index)   r1 = (a = p0 - p1, n)   r2 = (b = p0 - p2, 0)   r3 = (cross(a, b), 0)
+// leaf_inline = 1 (BVH, and kd-trees with few leaf references): records are stored in leaf order, a
+// leaf reference is ~(index of its first record) and n in the FIRST record of a leaf is the leaf's
+// triangle count.  leaf_inline = 0 (kd-trees, whose leaves repeat triangles many times): records
+// are stored in mesh order and a leaf reference is ~offset into `refs`, where refs[off] = n,
+// refs[off+1..off+n] = triangle indices in the reference's leaf order.
 //
 // Triangles: three float4 per triangle in `tri_pos` (vertex k in .xyz; the .w of vertex 0 holds
 // the material index as an int bit pattern), three float4 per triangle in `tri_nrm`, three
@@ -37,6 +47,7 @@ namespace pt {
 struct SceneGpu {
     const float4* nodes;
     const int* refs;
+    const float4* isect;
     const float4* tri_pos;
     const float4* tri_nrm;
     const float2* tri_uv;
@@ -49,6 +60,7 @@ struct SceneGpu {
     int n_nodes;
     int lds_nodes;  // nodes [0, lds_nodes) are staged in LDS by the trace kernels
     int n_tris;
+    int leaf_inline;  // layout of the leaves, see above
     int planes_ok;  // every box coordinate is 0 or at least 1e-17 in magnitude (reciprocal slab form allowed)
 };
 

@@ -8,6 +8,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -80,7 +81,7 @@ struct PtContext {
     int lds_nodes_opt = 256;
 
     // device scene
-    DeviceBuffer<float4> d_nodes, d_tri_pos, d_tri_nrm, d_mats;
+    DeviceBuffer<float4> d_nodes, d_isect, d_tri_pos, d_tri_nrm, d_mats;
     DeviceBuffer<float2> d_tri_uv;
     DeviceBuffer<int> d_refs;
     DeviceBuffer<uint8_t> d_texels;
@@ -212,13 +213,39 @@ int flatten_and_upload(PtContext* c) {
             }
         }
     }
+    // intersection records (layout: device_types.h); the arithmetic is the triangle test's own
+    const HostMesh& hm = c->mesh;
+    auto record = [&](int tri, int count, std::vector<float4>& out) {
+        const vec3 p0 = hm.p(tri, 0);
+        const vec3 a = p0 - hm.p(tri, 1);
+        const vec3 b = p0 - hm.p(tri, 2);
+        const vec3 ab = cross(a, b);
+        float fid, fcount;
+        memcpy(&fid, &tri, 4); memcpy(&fcount, &count, 4);
+        out.push_back(make_float4(p0.x, p0.y, p0.z, fid));
+        out.push_back(make_float4(a.x, a.y, a.z, fcount));
+        out.push_back(make_float4(b.x, b.y, b.z, 0.0f));
+        out.push_back(make_float4(ab.x, ab.y, ab.z, 0.0f));
+    };
+    // kd-tree leaves repeat triangles; their records are stored per leaf only while that stays small
+    // enough to live in the caches (64 bytes a reference), otherwise once per triangle behind `refs`
+    const bool kd = t.kind == 1 && t.refs.size() > 32768;
     std::vector<int> refs;
-    std::vector<int> leaf_ref(n, 0);
+    std::vector<float4> isect;
+    if (kd) {
+        for (int i = 0; i < hm.num_tris(); i++) record(i, 0, isect);
+    }
     auto leaf_reference = [&](int node) -> int {
         const HostTree::Node& nd = t.nodes[node];
-        const int off = (int)refs.size();
-        refs.push_back(nd.count);
-        for (int k = 0; k < nd.count; k++) refs.push_back(t.refs[nd.first + k]);
+        if (kd) {
+            const int off = (int)refs.size();
+            refs.push_back(nd.count);
+            for (int k = 0; k < nd.count; k++) refs.push_back(t.refs[nd.first + k]);
+            return ~off;
+        }
+        const int off = (int)(isect.size() / 4);
+        if (nd.count == 0) record(0, 0, isect);  // an empty leaf still needs a record to hold its count
+        for (int k = 0; k < nd.count; k++) record(t.refs[nd.first + k], k == 0 ? nd.count : 0, isect);
         return ~off;
     };
     std::vector<float4> nodes(order.size() * 4);
@@ -277,6 +304,7 @@ int flatten_and_upload(PtContext* c) {
 
     PT_HIP(c, c->d_nodes.upload(nodes.data(), nodes.size(), c->stream));
     PT_HIP(c, c->d_refs.upload(refs.data(), refs.size(), c->stream));
+    PT_HIP(c, c->d_isect.upload(isect.data(), isect.size(), c->stream));
     PT_HIP(c, c->d_tri_pos.upload(tp.data(), tp.size(), c->stream));
     PT_HIP(c, c->d_tri_nrm.upload(tn.data(), tn.size(), c->stream));
     PT_HIP(c, c->d_tri_uv.upload(tuv.data(), tuv.size(), c->stream));
@@ -286,7 +314,7 @@ int flatten_and_upload(PtContext* c) {
     PT_HIP(c, hipStreamSynchronize(c->stream));  // the staging vectors die with this scope
 
     SceneGpu& s = c->scene;
-    s.nodes = c->d_nodes.ptr; s.refs = c->d_refs.ptr;
+    s.nodes = c->d_nodes.ptr; s.refs = c->d_refs.ptr; s.isect = c->d_isect.ptr;
     s.tri_pos = c->d_tri_pos.ptr; s.tri_nrm = c->d_tri_nrm.ptr; s.tri_uv = c->d_tri_uv.ptr;
     s.mats = c->d_mats.ptr; s.texels = c->d_texels.ptr; s.env = c->d_env.ptr;
     s.env_w = c->env.w; s.env_h = c->env.h;
@@ -295,6 +323,7 @@ int flatten_and_upload(PtContext* c) {
     s.n_nodes = (int)order.size();
     s.lds_nodes = c->lds_nodes_opt < s.n_nodes ? c->lds_nodes_opt : s.n_nodes;
     s.n_tris = nt;
+    s.leaf_inline = kd ? 0 : 1;
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)
         for (int k = 0; k < 6; k++)
@@ -377,7 +406,9 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     b.seed = c->seed;
     b.n_slots = n_pixels * chunk;
     // workgroups sharing the batch: about 2048 camera samples each, at most the resident grid
-    int nb = (b.n_slots + 2047) / 2048;
+    int per_block = 2048;
+    if (const char* e = getenv("PT_SLOTS_PER_BLOCK")) { int v = atoi(e); if (v >= 64) per_block = v; }
+    int nb = (b.n_slots + per_block - 1) / per_block;
     nb = nb < 1 ? 1 : (nb > c->blocks ? c->blocks : nb);
     b.blocks = nb;
     b.slots_block = (((b.n_slots + 63) / 64 + nb - 1) / nb) * 64;  // runs of 64 samples dealt in rounds
@@ -468,7 +499,9 @@ int pt_create(int device, PtContext** out) {
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PT_ERR_HIP; }
     c->own_stream = true;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->blocks = prop.multiProcessorCount * 8;
+    int per_cu = 8;
+    if (const char* e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) per_cu = v; }
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->blocks = prop.multiProcessorCount * per_cu;
     if (c->d_totals.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         c->d_block_stats.ensure((size_t)c->blocks * DC_BLOCK_COUNT) != hipSuccess ||
         hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)) != hipSuccess) {
@@ -486,7 +519,7 @@ void pt_destroy(PtContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drain_spans(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    c->d_nodes.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
+    c->d_nodes.release(); c->d_isect.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
     c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
     for (int k = 0; k < 2; k++) { c->q_ray_o[k].release(); c->q_ray_d[k].release(); c->q_beta[k].release(); }
     c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release();

@@ -55,13 +55,15 @@ struct Best {
     int tri;
 };
 
-__device__ __forceinline__ void triangle_test(const SceneGpu& sc, int tri, vec3 o, vec3 d, Best& best) {
-    const float4 A = sc.tri_pos[3 * tri], B = sc.tri_pos[3 * tri + 1], C = sc.tri_pos[3 * tri + 2];
-    const vec3 p0 = v3(A.x, A.y, A.z);
-    const vec3 a = p0 - v3(B.x, B.y, B.z);
-    const vec3 b = p0 - v3(C.x, C.y, C.z);
-    const vec3 e = p0 - o;
-    const vec3 ab = cross(a, b);
+// TriangleMesh::raytraceTriangle (src/cs488.h:646-681) on an intersection record: the edge vectors
+// a, b and cross(a, b) come precomputed (they do not depend on the ray), the rest is evaluated here
+// in the reference's order.
+__device__ __forceinline__ void triangle_test(const float4& r0, const float4& r1, const float4& r2, const float4& r3,
+                                              vec3 o, vec3 d, Best& best) {
+    const vec3 a = v3(r1.x, r1.y, r1.z);
+    const vec3 b = v3(r2.x, r2.y, r2.z);
+    const vec3 ab = v3(r3.x, r3.y, r3.z);
+    const vec3 e = v3(r0.x, r0.y, r0.z) - o;
     const float D = dot(ab, d);
     if (D != 0) {
         const float Da = dot(cross(e, b), d);
@@ -72,7 +74,7 @@ __device__ __forceinline__ void triangle_test(const SceneGpu& sc, int tri, vec3 
         const float alpha = 1 - beta - gamma;
         const float t = Dc / D;
         if (0 <= alpha && alpha <= 1 && 0 <= beta && beta <= 1 && 0 <= gamma && gamma <= 1 && 0.0f <= t && t <= FLT_MAX) {
-            if (t < best.t) { best.t = t; best.beta = beta; best.gamma = gamma; best.tri = tri; }
+            if (t < best.t) { best.t = t; best.beta = beta; best.gamma = gamma; best.tri = __float_as_int(r0.w); }
         }
     }
 }
@@ -295,10 +297,22 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
         // ---- phase B: lanes standing on a leaf test its triangles in stored order ----
         if (have && cur < 0) {
             const int off = ~cur;
-            const int cnt = sc.refs[off];
-            for (int k = 1; k <= cnt; k++) {
-                if (COUNT) n_tri++;
-                triangle_test(sc, sc.refs[off + k], o, d, best);
+            if (KD && !sc.leaf_inline) {
+                const int cnt = sc.refs[off];
+                for (int k = 1; k <= cnt; k++) {
+                    if (COUNT) n_tri++;
+                    const float4* rec = sc.isect + 4 * (size_t)sc.refs[off + k];
+                    triangle_test(rec[0], rec[1], rec[2], rec[3], o, d, best);
+                }
+            } else {
+                const float4* rec = sc.isect + 4 * (size_t)off;
+                float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                const int cnt = __float_as_int(r1.w);
+                for (int k = 0; k < cnt; k++) {
+                    if (COUNT) n_tri++;
+                    triangle_test(r0, r1, r2, r3, o, d, best);
+                    if (k + 1 < cnt) { rec += 4; r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+                }
             }
             pop_or_finish();
         }
