@@ -406,9 +406,7 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     b.seed = c->seed;
     b.n_slots = n_pixels * chunk;
     // workgroups sharing the batch: about 2048 camera samples each, at most the resident grid
-    int per_block = 2048;
-    if (const char* e = getenv("PT_SLOTS_PER_BLOCK")) { int v = atoi(e); if (v >= 64) per_block = v; }
-    int nb = (b.n_slots + per_block - 1) / per_block;
+    int nb = (b.n_slots + 2047) / 2048;
     nb = nb < 1 ? 1 : (nb > c->blocks ? c->blocks : nb);
     b.blocks = nb;
     b.slots_block = (((b.n_slots + 63) / 64 + nb - 1) / nb) * 64;  // runs of 64 samples dealt in rounds
@@ -499,9 +497,8 @@ int pt_create(int device, PtContext** out) {
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PT_ERR_HIP; }
     c->own_stream = true;
     hipDeviceProp_t prop;
-    int per_cu = 8;
-    if (const char* e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) per_cu = v; }
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->blocks = prop.multiProcessorCount * per_cu;
+    // eight 256-lane workgroups per CU are resident at once with the kernels' register and LDS use
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->blocks = prop.multiProcessorCount * 8;
     if (c->d_totals.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         c->d_block_stats.ensure((size_t)c->blocks * DC_BLOCK_COUNT) != hipSuccess ||
         hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)) != hipSuccess) {

@@ -20,10 +20,13 @@
 //
 // Launch shape: one 256-lane workgroup per queue region; the region's length is read from device
 // memory (written by the previous stage), so the host never waits for a count.  A wave alternates
-// two phases: all lanes standing on interior nodes walk (slab tests only) until each has reached a
-// leaf or finished, then the lanes standing on leaves test their triangles.  Lanes whose ray is
-// finished take the next rays of the region through an LDS counter (one atomic per refill) as soon
-// as a quarter of the wave is idle.  The first `lds_nodes` tree nodes (the top levels; nodes are numbered breadth-first) are
+// two tight loops: the node phase, in which every lane standing on an interior node takes steps
+// (two slab tests, push, descend or pop) while the other lanes wait, and the leaf phase, in which
+// every lane standing on a leaf tests up to four of its triangles.  The node phase is left when
+// none of its lanes remain or when they are outnumbered k to 1 by the lanes waiting at a leaf, so
+// neither code path runs nearly empty because of one long walk or one large leaf.  Lanes whose ray
+// is finished take the next rays of the region through an LDS counter (one atomic per refill) as
+// soon as a quarter of the wave is idle.  The first `lds_nodes` tree nodes (the top levels; nodes are numbered breadth-first) are
 // copied into LDS by every workgroup that has work; the first LDS_STACK entries of every lane's
 // traversal stack live in LDS as well.
 #include <float.h>
@@ -96,19 +99,17 @@ __device__ __forceinline__ float div_by_recip(float a, float d, float r) {
     return __fmaf_rn(e, r, q0);
 }
 
+// Only called for rays that passed recip_ok: all six quotients are finite, so the reference's
+// swap / running-max / running-min sequence (src/cs488.h:541-560) reduces to plain min and max
+// (the sign of a zero may differ, which no comparison below or in the walk can see).
 __device__ __forceinline__ bool slab_test_recip(float lox, float loy, float loz, float hix, float hiy, float hiz,
                                                 vec3 o, vec3 d, vec3 r, float& t_entry) {
-    float tx1 = div_by_recip(lox - o.x, d.x, r.x), ty1 = div_by_recip(loy - o.y, d.y, r.y), tz1 = div_by_recip(loz - o.z, d.z, r.z);
-    float tx2 = div_by_recip(hix - o.x, d.x, r.x), ty2 = div_by_recip(hiy - o.y, d.y, r.y), tz2 = div_by_recip(hiz - o.z, d.z, r.z);
-    if (tx1 > tx2) { float s = tx1; tx1 = tx2; tx2 = s; }
-    if (ty1 > ty2) { float s = ty1; ty1 = ty2; ty2 = s; }
-    if (tz1 > tz2) { float s = tz1; tz1 = tz2; tz2 = s; }
-    float t1 = tx1; if (t1 < ty1) t1 = ty1; if (t1 < tz1) t1 = tz1;
-    float t2 = tx2; if (t2 > ty2) t2 = ty2; if (t2 > tz2) t2 = tz2;
+    const float tx1 = div_by_recip(lox - o.x, d.x, r.x), ty1 = div_by_recip(loy - o.y, d.y, r.y), tz1 = div_by_recip(loz - o.z, d.z, r.z);
+    const float tx2 = div_by_recip(hix - o.x, d.x, r.x), ty2 = div_by_recip(hiy - o.y, d.y, r.y), tz2 = div_by_recip(hiz - o.z, d.z, r.z);
+    const float t1 = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+    const float t2 = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
     t_entry = t1;
-    if (t1 > t2) return false;
-    if ((t1 < 0.0f) && (t2 < 0.0f)) return false;
-    return true;
+    return !(t1 > t2) && !((t1 < 0.0f) && (t2 < 0.0f));
 }
 
 // May the reciprocal form be used for this ray?  Needs, per axis: a finite direction component
@@ -160,6 +161,8 @@ __device__ __forceinline__ void node_step(const float4& q0, const float4& q1, co
 // The first LDS_STACK entries of a lane's traversal stack live in LDS (entry e of lane t at
 // [e * 256 + t]: consecutive lanes on consecutive banks), deeper ones in the lane's scratch array.
 enum { LDS_STACK = 12 };
+// Triangles a lane tests per visit of the leaf phase.
+enum { LEAF_BURST = 4 };
 
 template <bool KD, bool COUNT, int SLAB, bool DYNAMIC>
 __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
     int deep[TRACE_STACK - LDS_STACK];
     float deep_t[KD ? TRACE_STACK - LDS_STACK : 1];
     int sp = 0, cur = 0;
+    int leaf_k = 0, leaf_n = 0;  // next triangle of the leaf the lane stands on, and the leaf's size
     size_t slot = 0;
     bool have = false, fast_ok = false;
     bool drained = false;  // wave-uniform: the region has no unassigned ray left
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                                                                      : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
                 if (in_root) {  // src/cs488.h:1438, 1405
                     cur = sc.root_ref;
+                    leaf_k = 0;
                     have = true;
                 } else {
                     hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
@@ -261,10 +266,9 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
             }
         }
 
-        // ---- phase A: every lane standing on an interior node walks until it reaches a leaf ----
+        // ---- node phase: lanes on interior nodes walk until too few of them are left ----
+        // (leave when nobody walks, or when the walkers are fewer than 1/k of the lanes waiting at a leaf)
         while (true) {
-            // leave the phase when nobody stands on a node, or (leave_k > 0) when the lanes still
-            // walking are fewer than 1/leave_k of the lanes already waiting at a leaf
             const int walking = __popcll(__ballot(have && cur >= 0));
             if (walking == 0) break;
             if (leave_k > 0 && walking * leave_k < __popcll(__ballot(have && cur < 0))) break;
@@ -291,30 +295,35 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                     sp++;
                 }
                 if (st.descend) cur = st.next; else pop_or_finish();
+                leaf_k = 0;
             }
         }
 
-        // ---- phase B: lanes standing on a leaf test its triangles in stored order ----
+        // ---- leaf phase: every lane on a leaf tests up to LEAF_BURST of its triangles, in stored
+        // order (src/cs488.h:1677-1681, 1350-1354); a larger leaf is finished in the next round, so
+        // one big leaf does not hold the other lanes
         if (have && cur < 0) {
             const int off = ~cur;
             if (KD && !sc.leaf_inline) {
-                const int cnt = sc.refs[off];
-                for (int k = 1; k <= cnt; k++) {
+                if (leaf_k == 0) leaf_n = sc.refs[off];
+                const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
+                for (; leaf_k < stop; leaf_k++) {
                     if (COUNT) n_tri++;
-                    const float4* rec = sc.isect + 4 * (size_t)sc.refs[off + k];
+                    const float4* rec = sc.isect + 4 * (size_t)sc.refs[off + 1 + leaf_k];
                     triangle_test(rec[0], rec[1], rec[2], rec[3], o, d, best);
                 }
             } else {
-                const float4* rec = sc.isect + 4 * (size_t)off;
+                const float4* rec = sc.isect + 4 * (size_t)(off + leaf_k);
                 float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                const int cnt = __float_as_int(r1.w);
-                for (int k = 0; k < cnt; k++) {
+                if (leaf_k == 0) leaf_n = __float_as_int(r1.w);
+                const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
+                for (; leaf_k < stop; leaf_k++) {
                     if (COUNT) n_tri++;
                     triangle_test(r0, r1, r2, r3, o, d, best);
-                    if (k + 1 < cnt) { rec += 4; r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+                    if (leaf_k + 1 < stop) { rec += 4; r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
                 }
             }
-            pop_or_finish();
+            if (leaf_k >= leaf_n) { pop_or_finish(); leaf_k = 0; }
         }
     }
 
