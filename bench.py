@@ -221,21 +221,23 @@ def main():
     reducer = None
     if world > 1:
         from path_tracer_amd.distributed import FrameReducer, sample_share
-        delta = torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda")
+        deltas = [torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda") for _ in range(2)]
         master = torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
-        scene.use_external_accum(delta.data_ptr())
-        reducer = FrameReducer(dist, delta, master)
+        reducer = FrameReducer(dist, deltas, master)
         first, count = sample_share(args.spp * world, world, rank)
 
     def step():
         if world == 1:
             scene.pathtrace(args.spp)
         else:
-            reducer.begin_frame()
+            # frame k renders into buffer k % 2 while the reduce of frame k-1 is still in flight
+            scene.use_external_accum(reducer.begin_frame().data_ptr())
             scene.pathtrace_split(args.spp * world, first, count)
             reducer.reduce(args.spp * world)
 
     def fence():
+        if reducer is not None:
+            reducer.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

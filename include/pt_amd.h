@@ -161,7 +161,9 @@ int pt_synchronize(PtContext* ctx);
 int pt_download(PtContext* ctx, int which, float* dst);
 /* Device address of the accumulation buffer (W*H*3 floats), for a collective over it. */
 void* pt_accum_device_ptr(PtContext* ctx);
-/* Render into caller-owned device memory (W*H*3 floats) instead; NULL restores the internal one. */
+/* Render into caller-owned device memory (W*H*3 floats) instead; NULL restores the internal one.
+ * Takes effect for the launches issued after the call (no synchronisation), so a caller may
+ * alternate between two buffers and reduce one while the next frame renders into the other. */
 int pt_use_external_accum(PtContext* ctx, void* device_ptr);
 /* Image::save (src/cs488.h:219-232): clamp to [0,1], truncate to 8 bits, PNG, top row first. */
 int pt_save_png(PtContext* ctx, int which, const char* path);

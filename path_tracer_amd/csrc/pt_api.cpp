@@ -795,7 +795,7 @@ void* pt_accum_device_ptr(PtContext* c) { return c ? (void*)c->accum_ptr() : nul
 int pt_use_external_accum(PtContext* c, void* device_ptr) {
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
-    PT_HIP(c, hipStreamSynchronize(c->stream));
+    // no wait: everything that touches the buffers is ordered on the context's stream
     c->ext_accum = (float*)device_ptr;
     return PT_OK;
 }

@@ -17,35 +17,68 @@ def sample_share(spp_frame, world, rank):
 
 
 class FrameReducer:
-    """Per-frame exchange step.  `delta` is this rank's accumulation of ONE frame (the renderer
-    writes into it; cleared before every frame), `master` the progressive accumulation that only
-    the root keeps.  reduce() sums all ranks' deltas onto the root and adds the sum to master."""
+    """Per-frame exchange step with the reduce overlapped with the next frame's rendering.
 
-    def __init__(self, dist, delta, master=None, root=0, group=None):
-        self.dist, self.delta, self.master, self.root, self.group = dist, delta, master, root, group
+    `deltas` are two (or more) per-frame accumulation buffers of this rank; frame k is rendered
+    into deltas[k % len(deltas)] (begin_frame() clears it and returns it, the caller points the
+    renderer at it), reduce() starts the sum of that buffer over all ranks onto the root without
+    waiting for it, and the buffer is only waited for when its turn comes again (or in finish()).
+    On the root every completed sum is added to `master`, the progressive accumulation.  With one
+    buffer the exchange is synchronous.
+    """
+
+    def __init__(self, dist, deltas, master=None, root=0, group=None):
+        self.dist, self.master, self.root, self.group = dist, master, root, group
+        self.deltas = list(deltas) if isinstance(deltas, (list, tuple)) else [deltas]
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.total_samples = 0
+        self.frame_index = 0
+        self.pending = [None] * len(self.deltas)  # per buffer: (work handle or None, needs add)
         if self.rank == root and master is None:
             raise ValueError("the root rank needs a master accumulation buffer")
 
+    def _retire(self, slot):
+        """Waits for the reduce issued on buffer `slot` (if any) and folds it into master."""
+        p = self.pending[slot]
+        if p is None:
+            return
+        work = p
+        if work is not True:
+            work.wait()
+        if self.rank == self.root:
+            self.master.add_(self.deltas[slot])
+        self.pending[slot] = None
+
     def begin_frame(self):
-        self.delta.zero_()
+        slot = self.frame_index % len(self.deltas)
+        self._retire(slot)
+        self.deltas[slot].zero_()
+        return self.deltas[slot]
 
     def reduce(self, spp_frame):
-        if self.dist.is_initialized() and self.dist.get_world_size(self.group) > 1:
-            if self.delta.is_cuda and self.dist.get_backend(self.group) == "gloo":
+        slot = self.frame_index % len(self.deltas)
+        buf = self.deltas[slot]
+        work = True
+        if self.world > 1:
+            if buf.is_cuda and self.dist.get_backend(self.group) == "gloo":
                 # rehearsal path (gloo reduces host tensors only): stage through host memory
-                host = self.delta.cpu()
+                host = buf.cpu()
                 self.dist.reduce(host, dst=self.root, op=self.dist.ReduceOp.SUM, group=self.group)
-                self.delta.copy_(host)
+                buf.copy_(host)
             else:
-                self.dist.reduce(self.delta, dst=self.root, op=self.dist.ReduceOp.SUM, group=self.group)
+                work = self.dist.reduce(buf, dst=self.root, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.pending[slot] = work
         self.total_samples += spp_frame
-        if self.rank == self.root:
-            self.master.add_(self.delta)
+        self.frame_index += 1
+
+    def finish(self):
+        for slot in range(len(self.deltas)):
+            self._retire(slot)
 
     def frame(self):
-        """accumulation / total samples on the root (src/cs488.h:1860)."""
+        """accumulation / total samples on the root (src/cs488.h:1860), after all sums have landed."""
+        self.finish()
         if self.rank != self.root:
             return None
         return self.master / float(max(self.total_samples, 1))
