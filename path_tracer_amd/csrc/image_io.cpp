@@ -249,7 +249,7 @@ void quantise_image(const float* rgb_bottom_up, int w, int h, std::vector<uint8_
         for (int i = 0; i < w; i++) {
             for (int c = 0; c < 3; c++) {
                 float r = rgb_bottom_up[((size_t)i + (size_t)j * w) * 3 + c];
-                float clamped = r < 1.0f ? r : 1.0f;   // min(1, r) then max(.., 0): NaN ends as 0
+                float clamped = r < 1.0f ? r : 1.0f;   // min(1, r) then max(.., 0): NaN fails r < 1 and ends as 255
                 clamped = clamped > 0.0f ? clamped : 0.0f;
                 out[k++] = (uint8_t)(255.0f * clamped);  // gamma 1.0 is the identity (src/cs488.h:160-164)
             }
