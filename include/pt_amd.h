@@ -28,7 +28,7 @@ typedef enum PtStatus {
     PT_ERR_INVALID_OBJ = -3,  /* .obj parsed to zero triangles (src/cs488.h:714) */
     PT_ERR_NOT_READY = -4,    /* call order: mesh, build, resolution, then render */
     PT_ERR_HIP = -5,          /* a HIP runtime call failed; see pt_last_error */
-    PT_ERR_QUEUE_OVERFLOW = -6, /* forked paths outgrew the ray queues; raise PT_OPT_QUEUE_FACTOR */
+    PT_ERR_QUEUE_OVERFLOW = -6, /* forked paths outgrew the ray queues even for a batch of 64 samples */
     PT_ERR_TREE_DEPTH = -7,   /* accelerator deeper than the traversal stack */
     PT_ERR_UNSUPPORTED = -8
 } PtStatus;
@@ -59,7 +59,9 @@ enum {
     PT_OPT_COUNT_TESTS = 3,   /* 1: trace kernels count box and triangle tests (slower) */
     PT_OPT_PROFILE = 4,       /* 1: bracket every kernel with HIP events on the context's stream */
     PT_OPT_MAX_BATCH = 5,     /* most camera samples in flight in one wavefront batch */
-    PT_OPT_QUEUE_FACTOR = 6,  /* queue capacity = factor x batch (forked paths), default 4 */
+    PT_OPT_QUEUE_FACTOR = 6,  /* queue capacity = factor x batch (forked paths), default 4; a batch that
+                               * outgrows it adds nothing and is rendered again in halves at the next
+                               * pt_synchronize / pt_download / pt_get_counters (PT_CNT_REPAIRED) */
     PT_OPT_LDS_NODES = 7,     /* tree nodes staged in LDS by the trace kernels (0 = none) */
     PT_OPT_TRAVERSAL = 8      /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab quotients from
                                  the per-ray reciprocal plus one exact correction step instead of the division
@@ -76,6 +78,7 @@ enum {
     PT_CNT_NAN_SAMPLES = 4, /* samples dropped by the NaN check (src/cs488.h:1841-1858) */
     PT_CNT_HITS = 5,        /* closest-hit queries that found a triangle */
     PT_CNT_MAX_QUEUE = 6,   /* largest ray-queue population seen */
+    PT_CNT_REPAIRED = 7,    /* batches rendered again in halves after their ray queues overflowed */
     PT_CNT_COUNT = 8
 };
 
@@ -156,6 +159,10 @@ int pt_render_split(PtContext* ctx, int spp_frame, int first, int count);
 /* frame = accumulation / totalSamples (src/cs488.h:1860) */
 int pt_resolve(PtContext* ctx);
 int pt_total_samples(PtContext* ctx);
+/* Waits for the stream, then completes every batch whose ray queues overflowed (see
+ * PT_OPT_QUEUE_FACTOR) into the accumulation buffer that is current at the time of the call and
+ * resolves again.  A caller that hands external buffers to a collective and renders scenes whose
+ * paths fork heavily calls this before the collective. */
 int pt_synchronize(PtContext* ctx);
 /* which: 0 = accumulation buffer, 1 = frame buffer.  Synchronises. */
 int pt_download(PtContext* ctx, int which, float* dst);

@@ -22,7 +22,7 @@ ERR_INVALID_ARG, ERR_IO, ERR_INVALID_OBJ, ERR_NOT_READY, ERR_HIP, ERR_QUEUE_OVER
     -1, -2, -3, -4, -5, -6, -7, -8)
 
 OPT_SEED, OPT_MAX_LEVEL, OPT_COUNT_TESTS, OPT_PROFILE, OPT_MAX_BATCH, OPT_QUEUE_FACTOR, OPT_LDS_NODES, OPT_TRAVERSAL = range(1, 9)
-CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SAMPLES, CNT_NAN_SAMPLES, CNT_HITS, CNT_MAX_QUEUE = range(7)
+CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SAMPLES, CNT_NAN_SAMPLES, CNT_HITS, CNT_MAX_QUEUE, CNT_REPAIRED = range(8)
 CNT_COUNT = 8
 TIMER_RAYGEN, TIMER_TRACE, TIMER_SHADE, TIMER_ACCUM = range(4)
 TIMER_COUNT = 4

@@ -89,6 +89,9 @@ struct BatchGpu {
     int cap_block;     // queue entries owned by one workgroup
     int slots_block;   // most camera samples one workgroup generates
     int deal_shift;    // rotation of the run -> workgroup assignment per dealing round
+    int* overflow;     // the batch's flag: cleared by raygen, set by a workgroup whose queue region ran
+                       // full, read by accumulate (a flagged batch adds nothing and is rendered again
+                       // in smaller pieces by the host)
 };
 
 enum { TRACE_STACK = 64 };

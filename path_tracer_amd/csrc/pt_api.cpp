@@ -52,6 +52,14 @@ struct DeviceBuffer {
 
 }  // namespace
 
+// What is needed to render a batch again should its overflow flag turn out set.
+struct IssuedBatch {
+    CameraGpu cam;
+    int pixel0, n_pixels, sample0, chunk;
+    int flag;  // index into the flag ring
+};
+enum { FLAG_RING = 1024 };
+
 struct PtContext {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -94,6 +102,9 @@ struct PtContext {
     DeviceBuffer<float4> q_ray_o[2], q_ray_d[2], q_beta[2], d_hit, d_sample_rad;
     DeviceBuffer<int> d_qcount;
     DeviceBuffer<unsigned long long> d_totals, d_block_stats;
+    DeviceBuffer<int> d_batch_flags;      // FLAG_RING overflow flags, one per batch in flight
+    std::vector<IssuedBatch> issued;      // batches whose flags have not been looked at yet
+    uint64_t batch_seq = 0, repaired_batches = 0;
     size_t batch_alloc = 0;
     uint64_t batch_rays = 0;  // rays traced through pt_trace_batch
 
@@ -376,26 +387,8 @@ int read_block_stats(PtContext* c, unsigned long long out[DC_BLOCK_COUNT]) {
     return PT_OK;
 }
 
-int clear_block_stats(PtContext* c, bool overflow_only) {
-    if (!overflow_only) {
-        PT_HIP(c, hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)));
-        return PT_OK;
-    }
-    std::vector<unsigned long long> h((size_t)c->blocks * DC_BLOCK_COUNT);
-    PT_HIP(c, hipMemcpy(h.data(), c->d_block_stats.ptr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    for (int b = 0; b < c->blocks; b++) h[(size_t)b * DC_BLOCK_COUNT + DB_OVERFLOW] = 0;
-    PT_HIP(c, hipMemcpy(c->d_block_stats.ptr, h.data(), h.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-    return PT_OK;
-}
-
-int check_device_flags(PtContext* c) {
-    unsigned long long st[DC_BLOCK_COUNT];
-    int rc = read_block_stats(c, st);
-    if (rc != PT_OK) return rc;
-    if (st[DB_OVERFLOW]) {
-        (void)clear_block_stats(c, true);
-        return fail(c, PT_ERR_QUEUE_OVERFLOW, "ray queue overflow: paths were dropped; raise PT_OPT_QUEUE_FACTOR");
-    }
+int clear_block_stats(PtContext* c) {
+    PT_HIP(c, hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)));
     return PT_OK;
 }
 
@@ -412,6 +405,10 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     b.slots_block = (((b.n_slots + 63) / 64 + nb - 1) / nb) * 64;  // runs of 64 samples dealt in rounds
     b.deal_shift = nb > 2 ? ((int)(nb * 0.6180339887) | 1) : 0;
     b.cap_block = (int)((c->batch_alloc * (size_t)c->queue_factor) / (size_t)nb);
+    IssuedBatch rec;
+    rec.cam = cam; rec.pixel0 = pixel0; rec.n_pixels = n_pixels; rec.sample0 = sample0; rec.chunk = chunk;
+    rec.flag = (int)(c->batch_seq++ % FLAG_RING);
+    b.overflow = c->d_batch_flags.ptr + rec.flag;
     const LaunchCfg cfg = cfg_of(c);
     const int levels = c->max_level + 2;  // levels 0 .. maxLevel+1; the last one only resolves misses
     // every stage writes every workgroup's count of the next level, so the counts need no clearing
@@ -443,6 +440,56 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
         PT_HIP(c, launch_tally(cfg, c->d_qcount.ptr, levels, nb, c->d_totals.ptr));
     }
     c->samples_started += (uint64_t)b.n_slots;
+    c->issued.push_back(rec);
+    return PT_OK;
+}
+
+// Waits for the stream and renders every batch whose queues overflowed again, in halves (half the
+// samples per pixel, or half the pixels once a batch holds one sample per pixel): the queue memory
+// stays the same, so a workgroup's region doubles relative to its samples with every halving.  A
+// flagged batch added nothing to the image (accumulate_kernel), so the pieces complete it exactly.
+int settle(PtContext* c) {
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    bool repaired = false;
+    std::vector<IssuedBatch> todo;
+    while (!c->issued.empty() || !todo.empty()) {
+        if (!c->issued.empty()) {  // the stream is idle here
+            int flags[FLAG_RING];
+            PT_HIP(c, hipMemcpy(flags, c->d_batch_flags.ptr, sizeof(flags), hipMemcpyDeviceToHost));
+            for (const IssuedBatch& r : c->issued)
+                if (flags[r.flag]) todo.push_back(r);
+            c->issued.clear();
+        }
+        while (!todo.empty() && c->issued.size() + 2 <= FLAG_RING) {
+            const IssuedBatch r = todo.back();
+            todo.pop_back();
+            if ((size_t)r.n_pixels * r.chunk <= 64)
+                return fail(c, PT_ERR_QUEUE_OVERFLOW, "ray queue overflow on a batch of at most 64 samples; raise PT_OPT_QUEUE_FACTOR");
+            c->repaired_batches++;
+            repaired = true;
+            c->samples_started -= (uint64_t)r.n_pixels * r.chunk;  // counted again by the pieces
+            int rc;
+            if (r.chunk > 1) {
+                const int h = r.chunk / 2;
+                rc = run_batch(c, r.cam, r.pixel0, r.n_pixels, r.sample0, h);
+                if (rc == PT_OK) rc = run_batch(c, r.cam, r.pixel0, r.n_pixels, r.sample0 + h, r.chunk - h);
+            } else {
+                const int h = r.n_pixels / 2;
+                rc = run_batch(c, r.cam, r.pixel0, h, r.sample0, 1);
+                if (rc == PT_OK) rc = run_batch(c, r.cam, r.pixel0 + h, r.n_pixels - h, r.sample0, 1);
+            }
+            if (rc != PT_OK) return rc;
+        }
+        if (!c->issued.empty()) {
+            PT_HIP(c, hipStreamSynchronize(c->stream));
+            drain_spans(c);
+        }
+    }
+    if (repaired && c->width > 0 && c->total_samples > 0) {
+        PT_HIP(c, launch_resolve(cfg_of(c), c->accum_ptr(), c->d_frame.ptr, c->width * c->height, c->total_samples));
+        PT_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return PT_OK;
 }
 
@@ -468,6 +515,10 @@ int render_range(PtContext* c, int spp_frame, int first, int count) {
             const size_t np = p0 + pix_per_batch <= n_pixels ? pix_per_batch : n_pixels - p0;
             for (int s = 0; s < count; s += (int)chunk) {
                 const int ch = s + (int)chunk <= count ? (int)chunk : count - s;
+                if (c->issued.size() + 1 > FLAG_RING) {  // every flag of the ring is waiting to be read
+                    rc = settle(c);
+                    if (rc != PT_OK) return rc;
+                }
                 rc = run_batch(c, cam, (int)p0, (int)np, base + first + s, ch);
                 if (rc != PT_OK) return rc;
             }
@@ -500,6 +551,7 @@ int pt_create(int device, PtContext** out) {
     // eight 256-lane workgroups per CU are resident at once with the kernels' register and LDS use
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->blocks = prop.multiProcessorCount * 8;
     if (c->d_totals.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess ||
+        c->d_batch_flags.ensure(FLAG_RING) != hipSuccess || hipMemset(c->d_batch_flags.ptr, 0, FLAG_RING * sizeof(int)) != hipSuccess ||
         c->d_block_stats.ensure((size_t)c->blocks * DC_BLOCK_COUNT) != hipSuccess ||
         hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)) != hipSuccess) {
         pt_destroy(c);
@@ -519,7 +571,7 @@ void pt_destroy(PtContext* c) {
     c->d_nodes.release(); c->d_isect.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
     c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
     for (int k = 0; k < 2; k++) { c->q_ray_o[k].release(); c->q_ray_d[k].release(); c->q_beta[k].release(); }
-    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release();
+    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -539,6 +591,10 @@ int pt_set_stream(PtContext* c, void* hip_stream) {
 
 int pt_set_option(PtContext* c, int option, uint64_t value) {
     if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->issued.empty()) {  // batches in flight are completed under the settings they started with
+        int rc = settle(c);
+        if (rc != PT_OK) return rc;
+    }
     switch (option) {
         case PT_OPT_SEED: c->seed = value; break;
         case PT_OPT_MAX_LEVEL:
@@ -690,6 +746,10 @@ int pt_build(PtContext* c, int accel) {
     if (!c) return PT_ERR_INVALID_ARG;
     if (accel != PT_ACCEL_BVH && accel != PT_ACCEL_KD) return fail(c, PT_ERR_INVALID_ARG, "unknown accelerator kind");
     if (c->mesh.num_tris() == 0) return fail(c, PT_ERR_NOT_READY, "no mesh loaded");
+    if (!c->issued.empty()) {
+        int rc = settle(c);
+        if (rc != PT_OK) return rc;
+    }
     c->accel = accel;
     if (accel == PT_ACCEL_KD) build_kd(c->mesh, c->tree); else build_bvh(c->mesh, c->tree);
     if (c->device == PT_DEVICE_NONE) return PT_OK;  // tree available through pt_get_tree; not renderable
@@ -742,6 +802,7 @@ int pt_reset(PtContext* c) {
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
     const size_t n = (size_t)c->width * c->height * 3;
+    c->issued.clear();  // whatever overflowed belongs to the image that is being thrown away
     PT_HIP(c, launch_clear(cfg_of(c), c->accum_ptr(), n));
     PT_HIP(c, launch_clear(cfg_of(c), c->d_frame.ptr, n));
     c->total_samples = 0;
@@ -775,9 +836,7 @@ int pt_total_samples(PtContext* c) { return c ? c->total_samples : PT_ERR_INVALI
 int pt_synchronize(PtContext* c) {
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
-    PT_HIP(c, hipStreamSynchronize(c->stream));
-    drain_spans(c);
-    return check_device_flags(c);
+    return settle(c);
 }
 
 int pt_download(PtContext* c, int which, float* dst) {
@@ -896,18 +955,20 @@ int pt_get_counters(PtContext* c, uint64_t out[PT_CNT_COUNT]) {
     out[PT_CNT_NAN_SAMPLES] = d[DC_NAN];
     out[PT_CNT_HITS] = st[DB_HITS];
     out[PT_CNT_MAX_QUEUE] = d[DC_MAXQ];
+    out[PT_CNT_REPAIRED] = c->repaired_batches;
     return PT_OK;
 }
 
 int pt_reset_counters(PtContext* c) {
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
-    PT_HIP(c, hipStreamSynchronize(c->stream));
-    drain_spans(c);
+    int rc0 = settle(c);
+    if (rc0 != PT_OK) return rc0;
     PT_HIP(c, hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)));
-    int rc = clear_block_stats(c, false);
+    int rc = clear_block_stats(c);
     if (rc != PT_OK) return rc;
     c->samples_started = 0;
+    c->repaired_batches = 0;
     c->batch_rays = 0;
     for (int i = 0; i < PT_TIMER_COUNT; i++) { c->timer_ms[i] = 0; c->timer_launches[i] = 0; }
     return PT_OK;

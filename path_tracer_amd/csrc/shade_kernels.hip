@@ -236,7 +236,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
         const int last_len = last_run == runs - 1 ? b.n_slots - last_run * 64 : 64;
         written = (my_runs - 1) * 64 + last_len;
     }
-    if (threadIdx.x == 0) qcount[blk] = written;
+    if (threadIdx.x == 0) {
+        qcount[blk] = written;
+        if (blk == 0) *b.overflow = 0;
+    }
     for (int j = threadIdx.x; j < written; j += blockDim.x) {
         const int l = j >> 6;
         const int slot = (l * b.blocks + (int)((blk + (long long)l * b.deal_shift) % b.blocks)) * 64 + (j & 63);
@@ -436,13 +439,14 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
     if (threadIdx.x == 0) {
         const int produced = s_out;
         qcount_out[blk] = produced < b.cap_block ? produced : b.cap_block;
-        if (produced > b.cap_block) block_stats[(size_t)blk * DC_BLOCK_COUNT + DB_OVERFLOW] = 1;  // paths were dropped
+        if (produced > b.cap_block) *b.overflow = 1;  // paths were dropped: the batch will be repeated
     }
 }
 
 // ---- per pixel: add the batch's samples to the accumulation buffer (src/cs488.h:1854-1858) ----
 __global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float4* __restrict__ sample_rad,
                                                          float* __restrict__ accum, unsigned long long* __restrict__ totals) {
+    if (*b.overflow) return;  // incomplete batch: nothing of it may reach the image
     const int stride = gridDim.x * blockDim.x;
     unsigned int dropped = 0;
     for (int pl = blockIdx.x * blockDim.x + threadIdx.x; pl < b.n_pixels; pl += stride) {

@@ -143,3 +143,47 @@ def test_cli_fallbacks(gpu_device, tmp_path):
                                % (missing, missing))
     r = run_cli(scene_path("cornellbox.obj"), "--accel", "octree")
     assert r.returncode == 2
+
+
+@pytest.mark.gpu
+def test_overflowing_batches_are_rendered_again(gpu_device):
+    """Every surface translucent: a path forks at each hit (src/cs488.h:2036-2045), so a workgroup's
+    population outgrows a 2x queue.  Flagged batches add nothing and are rendered again in halves at
+    the next synchronisation; the image must equal the one rendered with queues that never overflow
+    (up to the order of the float atomics on a sample shared by forked paths), and both must agree
+    with the oracle statistically."""
+    def render(factor, max_batch):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        mats = s.materials()
+        for m in mats:
+            m.opacity = 0.5
+        s.set_materials(mats)
+        s.pre_calc(pta.BVH)
+        s.set_option(pta.OPT_QUEUE_FACTOR, factor)
+        s.set_option(pta.OPT_MAX_BATCH, max_batch)
+        s.set_resolution(64, 48)
+        for _ in range(2):
+            s.pathtrace(8)
+        img = s.accumulation_buffer()
+        c = s.counters()
+        return img, c
+
+    small, c_small = render(2, 64 * 48 * 8)
+    big, c_big = render(64, 64 * 48 * 8)
+    assert c_big[pta.CNT_REPAIRED] == 0
+    assert c_small[pta.CNT_REPAIRED] > 0
+    assert c_small[pta.CNT_SAMPLES] == c_big[pta.CNT_SAMPLES] == 64 * 48 * 16
+    assert np.allclose(small, big, rtol=2e-4, atol=1e-5)
+    # pixel batches (one sample per pixel per batch) take the other way of halving
+    pix, c_pix = render(2, 1024)
+    assert c_pix[pta.CNT_REPAIRED] > 0
+    assert np.allclose(pix, big, rtol=2e-4, atol=1e-5)
+
+    o = load_oracle_scene("cornellbox.obj", orc.BVH)
+    for i in range(o.num_materials()):
+        o.set_material(i, opacity=0.5)
+    o.build(orc.BVH)
+    o.reset(64, 48)
+    o.render(spp=16, frames=1, threads=8)
+    ref = o.image()
+    assert abs(big.mean() / 16 - ref.mean()) < 0.03 * ref.mean()
