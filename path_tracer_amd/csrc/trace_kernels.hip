@@ -30,6 +30,7 @@
 // copied into LDS by every workgroup that has work; the first LDS_STACK entries of every lane's
 // traversal stack live in LDS as well.
 #include <float.h>
+#include <limits.h>
 
 #include "device_types.h"
 #include "pt_math.h"
@@ -152,7 +153,7 @@ __device__ __forceinline__ void node_step(const float4& q0, const float4& q1, co
     const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
     st.push = hl && hr;
     st.descend = hl || hr;
-    const bool left_first = st.push ? (tl < tr) : hl;
+    const bool left_first = hl && (!hr || (tl < tr));  // both: nearer first, right on ties; one: that one
     st.next = left_first ? left : right;
     st.deferred = left_first ? right : left;
     st.deferred_t = left_first ? tr : tl;
@@ -164,7 +165,11 @@ enum { LDS_STACK = 12 };
 // Triangles a lane tests per visit of the leaf phase.
 enum { LEAF_BURST = 4 };
 
-template <bool KD, bool COUNT, int SLAB, bool DYNAMIC>
+// A lane's `cur`: >= 0 interior node, < 0 leaf (~offset of its first record), NO_RAY = no ray.
+enum : int { NO_RAY = INT_MIN };
+
+// ALL_LDS: every interior node is staged in LDS (small scenes), so the walk has no global node path.
+template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS>
 __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
                                                     const float4* __restrict__ ray_d, float4* __restrict__ hit,
                                                     const int* __restrict__ n_ptr, int n_fixed, int cap_block,
@@ -202,10 +207,10 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
     best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
     int deep[TRACE_STACK - LDS_STACK];
     float deep_t[KD ? TRACE_STACK - LDS_STACK : 1];
-    int sp = 0, cur = 0;
+    int sp = 0, cur = NO_RAY;
     int leaf_k = 0, leaf_n = 0;  // next triangle of the leaf the lane stands on, and the leaf's size
     size_t slot = 0;
-    bool have = false, fast_ok = false;
+    bool fast_ok = false;
     bool drained = false;  // wave-uniform: the region has no unassigned ray left
     const int refill_min = DYNAMIC ? 16 : 64;
 
@@ -213,12 +218,13 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
     auto pop_or_finish = [&]() {
         while (sp > 0) {
             sp--;
-            int ref;
+            // the LDS read is unconditional (clamped) and the rare deep entry overrides it, which
+            // keeps the common case a plain LDS load instead of a load through a generic pointer
+            const int e = sp < LDS_STACK ? sp : LDS_STACK - 1;
+            int ref = s_stack[e * 256 + tid];
             float t_ref = 0.0f;
-            if (sp < LDS_STACK) {
-                ref = s_stack[sp * 256 + tid];
-                if (KD) t_ref = s_stack_t[sp * 256 + tid];
-            } else {
+            if (KD) t_ref = s_stack_t[e * 256 + tid];
+            if (__builtin_expect(sp >= LDS_STACK, 0)) {
                 ref = deep[sp - LDS_STACK];
                 if (KD) t_ref = deep_t[sp - LDS_STACK];
             }
@@ -228,12 +234,12 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
         }
         if (best.tri >= 0) n_hit++;
         hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.beta, best.gamma);
-        have = false;
+        cur = NO_RAY;
     };
 
     while (true) {
         // ---- idle lanes take the next rays of the region, once enough of them are idle ----
-        const unsigned long long idle = __ballot(!have);
+        const unsigned long long idle = __ballot(cur == NO_RAY);
         const int n_idle = __popcll(idle);
         if (n_idle == 64 && drained) break;
         if (!drained && n_idle >= refill_min) {
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
             base = __shfl(base, 0);
             drained = base + n_idle >= n;
             const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
-            if (!have && j < n) {
+            if (cur == NO_RAY && j < n) {
                 slot = region + j;
                 const float4 ro = ray_o[slot], rd = ray_d[slot];
                 o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
@@ -259,7 +265,6 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                 if (in_root) {  // src/cs488.h:1438, 1405
                     cur = sc.root_ref;
                     leaf_k = 0;
-                    have = true;
                 } else {
                     hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
                 }
@@ -269,12 +274,12 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
         // ---- node phase: lanes on interior nodes walk until too few of them are left ----
         // (leave when nobody walks, or when the walkers are fewer than 1/k of the lanes waiting at a leaf)
         while (true) {
-            const int walking = __popcll(__ballot(have && cur >= 0));
+            const int walking = __popcll(__ballot(cur >= 0));
             if (walking == 0) break;
-            if (leave_k > 0 && walking * leave_k < __popcll(__ballot(have && cur < 0))) break;
-            if (have && cur >= 0) {
+            if (leave_k > 0 && walking * leave_k < __popcll(__ballot((unsigned int)cur > (unsigned int)NO_RAY))) break;
+            if (cur >= 0) {
                 float4 q0, q1, q2, q3;
-                if (cur < staged) {
+                if (ALL_LDS || cur < staged) {
                     q0 = lds_nodes[4 * cur]; q1 = lds_nodes[4 * cur + 1]; q2 = lds_nodes[4 * cur + 2]; q3 = lds_nodes[4 * cur + 3];
                 } else {
                     const float4* np = sc.nodes + 4 * (size_t)cur;
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                 if (SLAB == SLAB_RECIP && fast_ok) node_step<true>(q0, q1, q2, q3, o, d, inv, best.t, st);
                 else node_step<false>(q0, q1, q2, q3, o, d, inv, best.t, st);
                 if (st.push) {
-                    if (sp < LDS_STACK) {
+                    if (__builtin_expect(sp < LDS_STACK, 1)) {
                         s_stack[sp * 256 + tid] = st.deferred;
                         if (KD) s_stack_t[sp * 256 + tid] = st.deferred_t;
                     } else {
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
         // ---- leaf phase: every lane on a leaf tests up to LEAF_BURST of its triangles, in stored
         // order (src/cs488.h:1677-1681, 1350-1354); a larger leaf is finished in the next round, so
         // one big leaf does not hold the other lanes
-        if (have && cur < 0) {
+        if ((unsigned int)cur > (unsigned int)NO_RAY) {
             const int off = ~cur;
             if (KD && !sc.leaf_inline) {
                 if (leaf_k == 0) leaf_n = sc.refs[off];
@@ -368,8 +373,12 @@ template <bool KD, bool COUNT, int SLAB, bool DYNAMIC>
 void launch_variant(const LaunchCfg& cfg, const SceneGpu& scene, const float4* ray_o, const float4* ray_d, float4* hit,
                     const int* n_rays, int n_fixed, int grid_blocks, int cap_block, unsigned long long* block_stats, int leave_k) {
     const size_t lds = (size_t)scene.lds_nodes * 64;
-    hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene, ray_o,
-                       ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
+    if (scene.lds_nodes >= scene.n_nodes)
+        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, true>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
+                           ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
+    else
+        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, false>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
+                           ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
 }
 
 template <bool KD, bool COUNT>
