@@ -61,6 +61,7 @@ struct SceneGpu {
     int lds_nodes;  // nodes [0, lds_nodes) are staged in LDS by the trace kernels
     int n_tris;
     int leaf_inline;  // layout of the leaves, see above
+    int n_records;    // intersection records in `isect`
     int planes_ok;  // every box coordinate is 0 or at least 1e-17 in magnitude (reciprocal slab form allowed)
 };
 

@@ -335,6 +335,7 @@ int flatten_and_upload(PtContext* c) {
     s.lds_nodes = c->lds_nodes_opt < s.n_nodes ? c->lds_nodes_opt : s.n_nodes;
     s.n_tris = nt;
     s.leaf_inline = kd ? 0 : 1;
+    s.n_records = (int)(isect.size() / 4);
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)
         for (int k = 0; k < 6; k++)

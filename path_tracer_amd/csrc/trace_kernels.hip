@@ -168,7 +168,9 @@ enum { LEAF_BURST = 4 };
 // A lane's `cur`: >= 0 interior node, < 0 leaf (~offset of its first record), NO_RAY = no ray.
 enum : int { NO_RAY = INT_MIN };
 
-// ALL_LDS: every interior node is staged in LDS (small scenes), so the walk has no global node path.
+// ALL_LDS: every interior node and every (leaf-ordered) intersection record is staged in LDS --
+// small scenes -- so neither the walk nor the leaf phase has a global-memory path.
+enum { LDS_RECORDS_MAX = 256 };
 template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS>
 __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
                                                     const float4* __restrict__ ray_d, float4* __restrict__ hit,
@@ -192,6 +194,9 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
 
     const int staged = sc.lds_nodes;
     for (int k = threadIdx.x; k < staged * 4; k += blockDim.x) lds_nodes[k] = sc.nodes[k];
+    float4* lds_records = lds_nodes + 4 * staged;
+    if (ALL_LDS)
+        for (int k = threadIdx.x; k < sc.n_records * 4; k += blockDim.x) lds_records[k] = sc.isect[k];
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
             int ref = s_stack[e * 256 + tid];
             float t_ref = 0.0f;
             if (KD) t_ref = s_stack_t[e * 256 + tid];
+            asm volatile("" : "+v"(ref), "+v"(t_ref));  // keeps the two loads from being merged into one generic load
             if (__builtin_expect(sp >= LDS_STACK, 0)) {
                 ref = deep[sp - LDS_STACK];
                 if (KD) t_ref = deep_t[sp - LDS_STACK];
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                     triangle_test(rec[0], rec[1], rec[2], rec[3], o, d, best);
                 }
             } else {
-                const float4* rec = sc.isect + 4 * (size_t)(off + leaf_k);
+                const float4* rec = ALL_LDS ? lds_records + 4 * (off + leaf_k) : sc.isect + 4 * (size_t)(off + leaf_k);
                 float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                 if (leaf_k == 0) leaf_n = __float_as_int(r1.w);
                 const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
@@ -373,8 +379,9 @@ template <bool KD, bool COUNT, int SLAB, bool DYNAMIC>
 void launch_variant(const LaunchCfg& cfg, const SceneGpu& scene, const float4* ray_o, const float4* ray_d, float4* hit,
                     const int* n_rays, int n_fixed, int grid_blocks, int cap_block, unsigned long long* block_stats, int leave_k) {
     const size_t lds = (size_t)scene.lds_nodes * 64;
-    if (scene.lds_nodes >= scene.n_nodes)
-        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, true>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
+    if (scene.lds_nodes >= scene.n_nodes && scene.leaf_inline && scene.n_records <= LDS_RECORDS_MAX)
+        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, true>), dim3(grid_blocks), dim3(256),
+                           lds + (size_t)scene.n_records * 64, cfg.stream, scene,
                            ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
     else
         hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, false>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
