@@ -65,6 +65,9 @@ struct SceneGpu {
     int planes_ok;  // every box coordinate is 0 or at least 1e-17 in magnitude (reciprocal slab form allowed)
 };
 
+// float4 records per material: Kd|type, Ks|eta, Ke|opacity, roughness|texture w,h,offset, Kd/pi
+enum { MATERIAL_STRIDE = 5 };
+
 struct CameraGpu {
     float eye[3], u[3], v[3], w[3];
     float aspect_film;  // aspect * film size
@@ -90,6 +93,7 @@ struct BatchGpu {
     int cap_block;     // queue entries owned by one workgroup
     int slots_block;   // most camera samples one workgroup generates
     int deal_shift;    // rotation of the run -> workgroup assignment per dealing round
+    const uint64_t* keys;  // sampler key of each of the batch's `chunk` sample indices
     int* overflow;     // the batch's flag: cleared by raygen, set by a workgroup whose queue region ran
                        // full, read by accumulate (a flagged batch adds nothing and is rendered again
                        // in smaller pieces by the host)

@@ -102,6 +102,7 @@ struct PtContext {
     DeviceBuffer<float4> q_ray_o[2], q_ray_d[2], q_beta[2], d_hit, d_sample_rad;
     DeviceBuffer<int> d_qcount;
     DeviceBuffer<unsigned long long> d_totals, d_block_stats;
+    DeviceBuffer<uint64_t> d_keys;        // sampler keys of the batch in flight
     DeviceBuffer<int> d_batch_flags;      // FLAG_RING overflow flags, one per batch in flight
     std::vector<IssuedBatch> issued;      // batches whose flags have not been looked at yet
     uint64_t batch_seq = 0, repaired_batches = 0;
@@ -293,7 +294,7 @@ int flatten_and_upload(PtContext* c) {
             if (any_tex) tuv[3 * i + k] = make_float2(m.uv[6 * i + 2 * k], m.uv[6 * i + 2 * k + 1]);
         }
     }
-    std::vector<float4> mats(4 * m.materials.size());
+    std::vector<float4> mats(MATERIAL_STRIDE * m.materials.size());
     std::vector<uint8_t> texels;
     for (size_t i = 0; i < m.materials.size(); i++) {
         const HostMaterial& hm = m.materials[i];
@@ -304,10 +305,13 @@ int flatten_and_upload(PtContext* c) {
         }
         float ft, fw, fh, fo;
         memcpy(&ft, &type, 4); memcpy(&fw, &tw, 4); memcpy(&fh, &th, 4); memcpy(&fo, &off, 4);
-        mats[4 * i + 0] = make_float4(hm.Kd.x, hm.Kd.y, hm.Kd.z, ft);
-        mats[4 * i + 1] = make_float4(hm.Ks.x, hm.Ks.y, hm.Ks.z, hm.eta);
-        mats[4 * i + 2] = make_float4(hm.Ke.x, hm.Ke.y, hm.Ke.z, hm.opacity);
-        mats[4 * i + 3] = make_float4(hm.roughness, fw, fh, fo);
+        float4* rec = &mats[MATERIAL_STRIDE * i];
+        rec[0] = make_float4(hm.Kd.x, hm.Kd.y, hm.Kd.z, ft);
+        rec[1] = make_float4(hm.Ks.x, hm.Ks.y, hm.Ks.z, hm.eta);
+        rec[2] = make_float4(hm.Ke.x, hm.Ke.y, hm.Ke.z, hm.opacity);
+        rec[3] = make_float4(hm.roughness, fw, fh, fo);
+        const vec3 lambert = hm.Kd / PT_PI;  // Material::BRDF (src/cs488.h:417-428)
+        rec[4] = make_float4(lambert.x, lambert.y, lambert.z, 0.0f);
     }
     for (int id : m.mat) {
         if (id < 0 || id >= (int)m.materials.size()) return fail(c, PT_ERR_INVALID_ARG, "triangle with a material index outside the material table");
@@ -410,6 +414,8 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     rec.cam = cam; rec.pixel0 = pixel0; rec.n_pixels = n_pixels; rec.sample0 = sample0; rec.chunk = chunk;
     rec.flag = (int)(c->batch_seq++ % FLAG_RING);
     b.overflow = c->d_batch_flags.ptr + rec.flag;
+    PT_HIP(c, c->d_keys.ensure((size_t)(chunk > 1024 ? chunk : 1024)));
+    b.keys = c->d_keys.ptr;
     const LaunchCfg cfg = cfg_of(c);
     const int levels = c->max_level + 2;  // levels 0 .. maxLevel+1; the last one only resolves misses
     // every stage writes every workgroup's count of the next level, so the counts need no clearing
@@ -572,7 +578,7 @@ void pt_destroy(PtContext* c) {
     c->d_nodes.release(); c->d_isect.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
     c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
     for (int k = 0; k < 2; k++) { c->q_ray_o[k].release(); c->q_ray_d[k].release(); c->q_beta[k].release(); }
-    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release();
+    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release(); c->d_keys.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

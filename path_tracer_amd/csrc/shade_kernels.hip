@@ -30,6 +30,7 @@
 // prefix count for each lane's entry.  No global atomic is involved.
 #include <float.h>
 
+#include "device_math.h"
 #include "device_types.h"
 #include "pt_math.h"
 
@@ -63,19 +64,23 @@ struct Sampler {
     }
 };
 
-__device__ __forceinline__ Sampler make_sampler(uint64_t seed, int global_sample, int pixel, uint32_t bits) {
+__device__ __forceinline__ uint64_t sample_key(uint64_t seed, int global_sample) {
+    return mix64(seed ^ mix64((uint64_t)(uint32_t)global_sample)) | 1ull;
+}
+
+__device__ __forceinline__ Sampler make_sampler(uint64_t key, int pixel, uint32_t bits) {
     Sampler s;
-    s.key = mix64(seed ^ mix64((uint64_t)(uint32_t)global_sample)) | 1ull;
+    s.key = key;
     s.base = ((uint64_t)(uint32_t)pixel << 32) | (uint64_t)(bits & 0xffffff00u);
     s.dim = bits & 0xffu;
     return s;
 }
 
-// slot -> (pixel, global sample index)
-__device__ __forceinline__ void slot_to_sample(const BatchGpu& b, int slot, int& pixel, int& sample) {
+// slot -> (pixel, index of the sample within the batch's chunk)
+__device__ __forceinline__ void slot_to_sample(const BatchGpu& b, int slot, int& pixel, int& k) {
     const int pl = slot / b.chunk;
     pixel = b.pixel0 + pl;
-    sample = b.sample0 + (slot - pl * b.chunk);
+    k = slot - pl * b.chunk;
 }
 
 // Reserves queue entries for the lanes of one wave: every lane passes how many records it emits
@@ -134,7 +139,7 @@ __device__ __forceinline__ vec3 apply_transposed(const Frame3& m, vec3 v) {
 __device__ __forceinline__ Frame3 frame_about(vec3 z) {
     const vec3 ref = fabsf(dot(z, v3(0.0f, 1.0f, 0.0f))) > 0.99f ? v3(0.0f, 0.0f, 1.0f) : v3(0.0f, 1.0f, 0.0f);
     Frame3 m;
-    m.cx = normalize(cross(ref, z));
+    m.cx = normalize_fast(cross(ref, z));
     m.cy = cross(z, m.cx);
     m.cz = z;
     return m;
@@ -143,14 +148,13 @@ __device__ __forceinline__ Frame3 frame_about(vec3 z) {
 // cosineWeightedHemisphereSample (src/cs488.h:1994-2016)
 __device__ __forceinline__ vec3 cosine_direction(vec3 w, float u1, float u2) {
     const float r = sqrtf(u1);
-    const float theta = 2.0f * PT_PI * u2;
-    const float x = r * cosf(theta);
-    const float y = r * sinf(theta);
+    const float x = r * cos_turns(u2);  // theta = 2 pi u2
+    const float y = r * sin_turns(u2);
     const float z = sqrtf(1.0f - u1);
     const vec3 up = fabsf(w.z) < 0.999f ? v3(0.0f, 0.0f, 1.0f) : v3(1.0f, 0.0f, 0.0f);
-    const vec3 tg = normalize(cross(up, w));
+    const vec3 tg = normalize_fast(cross(up, w));
     const vec3 bt = cross(w, tg);
-    return normalize(tg * x + bt * y + w * z);
+    return normalize_fast(tg * x + bt * y + w * z);
 }
 
 // sampleHalfVector (src/cs488.h:2100-2130)
@@ -158,47 +162,50 @@ __device__ __forceinline__ vec3 half_vector(vec3 n, vec3 view, float rough, floa
     const Frame3 wfg = frame_about(n);
     const float alpha = rough * rough;
     const vec3 vg = apply_transposed(wfg, view);
-    const vec3 vs = normalize(v3(alpha * vg.x, alpha * vg.y, vg.z));
+    const vec3 vs = normalize_fast(v3(alpha * vg.x, alpha * vg.y, vg.z));
     const float area_green = vs.z;
-    const float pb = 1 / (1.0f + area_green);
+    const float pb = exact_reciprocal(1.0f + area_green);
     const float pg = 1 - pb;
-    const float phi = (rb < pb) ? rb / pb * PT_PI : PT_PI + (rb - pb) / pg * PT_PI;
+    const float phi = (rb < pb) ? divide1(rb, pb) * PT_PI : PT_PI + divide1(rb - pb, pg) * PT_PI;
     const float r = sqrtf(ra);
-    const float x = r * cosf(phi);
-    const float y = r * sinf(phi) * (rb < pb ? 1.0f : area_green);
+    const float turns = phi * (0.5f / PT_PI);
+    const float x = r * cos_turns(turns);
+    const float y = r * sin_turns(turns) * (rb < pb ? 1.0f : area_green);
     const float z = sqrtf(fmaxf(0.0f, 1.0f - x * x - y * y));
     const vec3 ms = apply(frame_about(vs), v3(x, y, z));
     const vec3 mg = v3(alpha * ms.x, alpha * ms.y, fmaxf(0.0f, ms.z));
-    return normalize(apply(wfg, mg));
+    return normalize_fast(apply(wfg, mg));
 }
 
 // cookTorranceReflectance with schlickFresnel, normalDistributionGGX, geometricAttenuation
 // (src/cs488.h:2050-2088)
 __device__ __forceinline__ float cook_torrance(vec3 view, vec3 light, vec3 n, float rough, float eta) {
-    const vec3 hv = normalize(view + light);
+    const vec3 hv = normalize_fast(view + light);
     const float nl = saturate(dot(n, light));
     const float nv = saturate(dot(n, view));
     const float nh = saturate(dot(n, hv));
     const float vh = saturate(dot(view, hv));
     const float es = eta - 1, ep = eta + 1;
-    const float f0 = (es * es) / (ep * ep);
-    const float F = f0 + (1 - f0) * powf(1 - vh, 5);
+    const float f0 = divide1(es * es, ep * ep);
+    const float omv = 1 - vh, omv2 = omv * omv;
+    const float F = f0 + (1 - f0) * (omv2 * omv2 * omv);
     const float a = rough * rough;
     const float a2 = a * a;
     const float den = nh * nh * (a2 - 1.0f) + 1.0f;
-    const float D = a2 / (PT_PI * den * den);
-    const float g1 = 2 * nh * nv / vh;
-    const float g2 = 2 * nh * nl / vh;
+    const float D = divide1(a2, PT_PI * den * den);
+    const float rvh = exact_reciprocal(vh);
+    const float g1 = div_by_recip(2 * nh * nv, vh, rvh);
+    const float g2 = div_by_recip(2 * nh * nl, vh, rvh);
     const float G = fminf(1.0f, fminf(g1, g2));
-    const float spec = (F * D * G) / (4.0f * nv * nl + PT_EPSILON);
+    const float spec = divide1(F * D * G, 4.0f * nv * nl + PT_EPSILON);
     return saturate(spec);
 }
 
 // fresnel (src/cs488.h:1906-1910)
 __device__ __forceinline__ float fresnel_unpolarised(float e1, float e2, float ci, float co) {
-    const float rs = (e1 * ci - e2 * co) / (e1 * ci + e2 * co);
-    const float rt = (e1 * co - e2 * ci) / (e1 * co + e2 * ci);
-    return (powf(rs, 2) + powf(rt, 2)) / 2;
+    const float rs = divide1(e1 * ci - e2 * co, e1 * ci + e2 * co);
+    const float rt = divide1(e1 * co - e2 * ci, e1 * co + e2 * ci);
+    return (rs * rs + rt * rt) / 2;
 }
 
 // Material::fetchTexture (src/cs488.h:402-414)
@@ -243,21 +250,28 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
     for (int j = threadIdx.x; j < written; j += blockDim.x) {
         const int l = j >> 6;
         const int slot = (l * b.blocks + (int)((blk + (long long)l * b.deal_shift) % b.blocks)) * 64 + (j & 63);
-        int pixel, sample;
-        slot_to_sample(b, slot, pixel, sample);
+        int pixel, k;
+        slot_to_sample(b, slot, pixel, k);
         const int px = pixel % cam.width, py = pixel / cam.width;
-        Sampler rng = make_sampler(b.seed, sample, pixel, 1u << 8);
+        Sampler rng = make_sampler(b.keys[k], pixel, 1u << 8);
         const float r1 = rng.next();
         const float r2 = rng.next();
         const float U = (px + (r1 * 2 - 1)) / float(cam.width) - 0.5f;
         const float V = (py + (r2 * 2 - 1)) / float(cam.height) - 0.5f;
         const vec3 pix = eye + float(cam.aspect_film * U) * cu + float(cam.film * V) * cv - cam.dist * cw;
-        const vec3 d = normalize(pix - eye);
+        const vec3 d = normalize_fast(pix - eye);
         out.ray_o[region + j] = make_float4(eye.x, eye.y, eye.z, 1.0f);
         out.ray_d[region + j] = make_float4(d.x, d.y, d.z, __uint_as_float((1u << 8) | rng.dim));
         out.beta[region + j] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(slot));
         sample_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
+}
+
+// Sampler keys of the batch's sample indices (they depend on the seed and the global sample index
+// only, so they are hashed once per batch instead of once per path and bounce).
+__global__ void sample_keys_kernel(uint64_t seed, int sample0, int chunk, uint64_t* __restrict__ keys) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < chunk) keys[k] = sample_key(seed, sample0 + k);
 }
 
 // ---- one bounce of shading for every path in the queue ----
@@ -302,22 +316,23 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
             } else if (level > max_level) {
                 ended = true;
             } else {
-                int pixel, sample;
-                slot_to_sample(b, slot, pixel, sample);
-                Sampler rng = make_sampler(b.seed, sample, pixel, bits);
+                int pixel, k;
+                slot_to_sample(b, slot, pixel, k);
+                Sampler rng = make_sampler(b.keys[k], pixel, bits);
 
                 // hit record: interpolated position, shading normal, texcoords (src/cs488.h:671-675)
                 const float hb = h.z, hg = h.w, ha = 1 - hb - hg;
                 const float4 P0 = sc.tri_pos[3 * tri], P1 = sc.tri_pos[3 * tri + 1], P2 = sc.tri_pos[3 * tri + 2];
                 const float4 N0 = sc.tri_nrm[3 * tri], N1 = sc.tri_nrm[3 * tri + 1], N2 = sc.tri_nrm[3 * tri + 2];
-                vec3 N = normalize(ha * v3(N0.x, N0.y, N0.z) + hb * v3(N1.x, N1.y, N1.z) + hg * v3(N2.x, N2.y, N2.z));
+                vec3 N = normalize_fast(ha * v3(N0.x, N0.y, N0.z) + hb * v3(N1.x, N1.y, N1.z) + hg * v3(N2.x, N2.y, N2.z));
                 const vec3 P = ha * v3(P0.x, P0.y, P0.z) + hb * v3(P1.x, P1.y, P1.z) + hg * v3(P2.x, P2.y, P2.z);
                 const bool backface = dot(d, N) > 0;  // src/cs488.h:1770-1773
                 if (backface) N = -N;
                 const vec3 view = -d;
 
                 const int mid = __float_as_int(P0.w);
-                const float4 m0 = sc.mats[4 * mid], m1 = sc.mats[4 * mid + 1], m2 = sc.mats[4 * mid + 2], m3 = sc.mats[4 * mid + 3];
+                const float4* mat = sc.mats + MATERIAL_STRIDE * mid;
+                const float4 m0 = mat[0], m1 = mat[1], m2 = mat[2], m3 = mat[3];
                 const int type = __float_as_int(m0.w);
                 const vec3 Kd = v3(m0.x, m0.y, m0.z), Ks = v3(m1.x, m1.y, m1.z), Ke = v3(m2.x, m2.y, m2.z);
                 const float eta = m1.w, opacity = m2.w, rough = m3.x;
@@ -326,7 +341,8 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
                 // HitInfo::surfaceColor (src/cs488.h:473-475), Lambertian only (Material::BRDF :417-428)
                 vec3 colour = v3(0.0f);
                 if (type == 0) {
-                    colour = Kd / PT_PI;
+                    const float4 m4 = mat[4];
+                    colour = v3(m4.x, m4.y, m4.z);  // Kd / pi, divided on the host
                     if (tw > 0) {
                         const float2 T0 = sc.tri_uv[3 * tri], T1 = sc.tri_uv[3 * tri + 1], T2 = sc.tri_uv[3 * tri + 2];
                         const float tu = ha * T0.x + hb * T1.x + hg * T2.x;
@@ -351,14 +367,14 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
                     if (ct < PT_EPSILON) {
                         ended = true;
                     } else {
-                        const float p = ct / PT_PI;
+                        const float p = div_by_recip(ct, PT_PI, 1.0f / PT_PI);
                         const bool translucent = opacity < 1.0f - PT_EPSILON;
                         const vec3 weight = translucent ? beta * opacity : beta;
                         if (Ke.x != 0.0f || Ke.y != 0.0f || Ke.z != 0.0f) add_radiance(sample_rad, slot, weight * Ke);
                         emit0 = true;
                         o0 = P + PT_EPSILON * N;
                         d0 = wo;
-                        b0 = weight * (colour * ct / p);
+                        b0 = weight * divide3(colour * ct, p);
                         scale0 = p;
                         if (translucent) {
                             emit1 = true;
@@ -371,7 +387,7 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
                     const float ra = rng.next();
                     const float rb = rng.next();
                     const vec3 hv = half_vector(N, view, rough, ra, rb);
-                    const vec3 light = normalize(reflect_about(-view, hv));
+                    const vec3 light = normalize_fast(reflect_about(-view, hv));
                     const float ln = dot(light, N);
                     if (ln < PT_EPSILON) {
                         ended = true;
@@ -386,13 +402,14 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
                     const vec3 wi = d;
                     const float wn = dot(wi, N);
                     const float e1 = backface ? eta : PT_ETA_AIR, e2 = backface ? PT_ETA_AIR : eta;
-                    const float under = 1 - powf(e1 / e2, 2) * (1 - powf(wn, 2));
+                    const float ratio = divide1(e1, e2);
+                    const float under = 1 - (ratio * ratio) * (1 - wn * wn);
                     bool reflect = under < 0;
                     vec3 rdir = v3(0.0f);
                     if (!reflect) {
-                        rdir = (e1 / e2) * (wi - wn * N) - (sqrtf(under) * N);
-                        const float ci = wn / (length(wi) * length(N));
-                        const float co = dot(N, rdir) / (length(N) * length(rdir));
+                        rdir = ratio * (wi - wn * N) - (sqrtf(under) * N);
+                        const float ci = divide1(wn, length(wi) * length(N));
+                        const float co = divide1(dot(N, rdir), length(N) * length(rdir));
                         const float R = fresnel_unpolarised(e1, e2, ci, co);
                         if (rng.next() < R) reflect = true;
                     }
@@ -502,6 +519,8 @@ __global__ void clear_kernel(float* buf, size_t n) {
 
 hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const BatchGpu& batch, QueueSet out,
                          float4* sample_rad, int* qcount) {
+    hipLaunchKernelGGL(sample_keys_kernel, dim3((batch.chunk + 255) / 256), dim3(256), 0, cfg.stream, batch.seed, batch.sample0,
+                       batch.chunk, const_cast<uint64_t*>(batch.keys));
     hipLaunchKernelGGL(raygen_kernel, dim3(batch.blocks), dim3(256), 0, cfg.stream, cam, batch, out, sample_rad, qcount);
     return hipGetLastError();
 }

@@ -32,6 +32,7 @@
 #include <float.h>
 #include <limits.h>
 
+#include "device_math.h"
 #include "device_types.h"
 #include "pt_math.h"
 
@@ -61,7 +62,11 @@ struct Best {
 
 // TriangleMesh::raytraceTriangle (src/cs488.h:646-681) on an intersection record: the edge vectors
 // a, b and cross(a, b) come precomputed (they do not depend on the ray), the rest is evaluated here
-// in the reference's order.
+// in the reference's order.  The three quotients by the determinant are true divisions in the
+// reference; FAST_DIV forms them from the exact reciprocal whenever the determinant and the three
+// numerators are in a range in which no intermediate overflows or becomes subnormal (a zero
+// numerator is left to the division so that the sign of a zero quotient is the reference's).
+template <bool FAST_DIV>
 __device__ __forceinline__ void triangle_test(const float4& r0, const float4& r1, const float4& r2, const float4& r3,
                                               vec3 o, vec3 d, Best& best) {
     const vec3 a = v3(r1.x, r1.y, r1.z);
@@ -73,10 +78,20 @@ __device__ __forceinline__ void triangle_test(const float4& r0, const float4& r1
         const float Da = dot(cross(e, b), d);
         const float Db = dot(cross(a, e), d);
         const float Dc = dot(ab, e);
-        const float beta = Da / D;
-        const float gamma = Db / D;
+        float beta, gamma, t;
+        const float lo = fminf(fminf(fabsf(Da), fabsf(Db)), fabsf(Dc));
+        const float hi = fmaxf(fmaxf(fabsf(Da), fabsf(Db)), fabsf(Dc));
+        if (FAST_DIV && lo >= 1e-22f && hi <= 1e15f && fabsf(D) >= 1e-15f && fabsf(D) <= 1e15f) {
+            const float r = exact_reciprocal(D);
+            beta = div_by_recip(Da, D, r);
+            gamma = div_by_recip(Db, D, r);
+            t = div_by_recip(Dc, D, r);
+        } else {
+            beta = Da / D;
+            gamma = Db / D;
+            t = Dc / D;
+        }
         const float alpha = 1 - beta - gamma;
-        const float t = Dc / D;
         if (0 <= alpha && alpha <= 1 && 0 <= beta && beta <= 1 && 0 <= gamma && gamma <= 1 && 0.0f <= t && t <= FLT_MAX) {
             if (t < best.t) { best.t = t; best.beta = beta; best.gamma = gamma; best.tri = __float_as_int(r0.w); }
         }
@@ -93,12 +108,6 @@ __device__ __forceinline__ void triangle_test(const float4& r0, const float4& r1
 //   promised from their origin and direction alone (`recip_ok` below) use the division form, so both
 //   settings give bit-identical entry distances and therefore the identical walk.
 enum { SLAB_DIVIDE = 0, SLAB_RECIP = 1 };
-
-__device__ __forceinline__ float div_by_recip(float a, float d, float r) {
-    const float q0 = a * r;
-    const float e = __fmaf_rn(-q0, d, a);
-    return __fmaf_rn(e, r, q0);
-}
 
 // Only called for rays that passed recip_ok: all six quotients are finite, so the reference's
 // swap / running-max / running-min sequence (src/cs488.h:541-560) reduces to plain min and max
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                 sp = 0;
                 if (SLAB == SLAB_RECIP) {
                     fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
-                    if (fast_ok) inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
                 }
                 float t_root;
                 if (COUNT) n_box++;
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                 for (; leaf_k < stop; leaf_k++) {
                     if (COUNT) n_tri++;
                     const float4* rec = sc.isect + 4 * (size_t)sc.refs[off + 1 + leaf_k];
-                    triangle_test(rec[0], rec[1], rec[2], rec[3], o, d, best);
+                    triangle_test<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, best);
                 }
             } else {
                 const float4* rec = ALL_LDS ? lds_records + 4 * (off + leaf_k) : sc.isect + 4 * (size_t)(off + leaf_k);
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                 const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
                 for (; leaf_k < stop; leaf_k++) {
                     if (COUNT) n_tri++;
-                    triangle_test(r0, r1, r2, r3, o, d, best);
+                    triangle_test<SLAB == SLAB_RECIP>(r0, r1, r2, r3, o, d, best);
                     if (leaf_k + 1 < stop) { rec += 4; r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
                 }
             }
