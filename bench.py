@@ -110,6 +110,10 @@ def make_scene(pta, args, device, accel):
     if cam:
         s.set_camera(**cam)
     s.pre_calc(accel)
+    if args.lds_nodes is not None:
+        s.set_option(pta.OPT_LDS_NODES, args.lds_nodes)
+    if args.traversal is not None:
+        s.set_option(pta.OPT_TRAVERSAL, args.traversal)
     s.set_resolution(args.width, args.height)
     return s
 
@@ -182,6 +186,8 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per frame and per GPU")
+    ap.add_argument("--lds-nodes", type=int, default=None, help="tree nodes staged in LDS by the trace kernel (PT_OPT_LDS_NODES)")
+    ap.add_argument("--traversal", type=lambda v: int(v, 0), default=None, help="PT_OPT_TRAVERSAL bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kd", action="store_true", help="skip the short kd-tree comparison run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -179,7 +179,7 @@ enum : int { NO_RAY = INT_MIN };
 
 // ALL_LDS: every interior node and every (leaf-ordered) intersection record is staged in LDS --
 // small scenes -- so neither the walk nor the leaf phase has a global-memory path.
-enum { LDS_RECORDS_MAX = 256 };
+enum { LDS_RECORDS_MAX = 320 };
 template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS>
 __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
                                                     const float4* __restrict__ ray_d, float4* __restrict__ hit,
