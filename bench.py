@@ -114,6 +114,8 @@ def make_scene(pta, args, device, accel):
         s.set_option(pta.OPT_LDS_NODES, args.lds_nodes)
     if args.traversal is not None:
         s.set_option(pta.OPT_TRAVERSAL, args.traversal)
+    if args.tail_level is not None:
+        s.set_option(pta.OPT_TAIL_LEVEL, args.tail_level)
     s.set_resolution(args.width, args.height)
     return s
 
@@ -187,6 +189,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per frame and per GPU")
     ap.add_argument("--lds-nodes", type=int, default=None, help="tree nodes staged in LDS by the trace kernel (PT_OPT_LDS_NODES)")
+    ap.add_argument("--tail-level", type=int, default=None, help="PT_OPT_TAIL_LEVEL (0 = one launch per level)")
     ap.add_argument("--traversal", type=lambda v: int(v, 0), default=None, help="PT_OPT_TRAVERSAL bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kd", action="store_true", help="skip the short kd-tree comparison run")
@@ -274,6 +277,8 @@ def main():
     c = scene.counters()
     ms, launches = scene.timers()
     rays_local = float(c[pta.CNT_RAYS])
+    rays_tail = float(c[pta.CNT_TAIL_RAYS])     # traced by the fused launch of the deep levels, timed separately
+    rays_kernel = rays_local - rays_tail        # traced by trace_kernel launches
     max_queue = c[pta.CNT_MAX_QUEUE]
 
     if world > 1:
@@ -292,7 +297,7 @@ def main():
         b_ray = bytes_per_ray(n_box, n_tri, hit_frac)
         trace_s = ms[pta.TIMER_TRACE] * 1e-3
         traffic, traffic_source = measured_traffic(args, world)
-        achieved = rays_local * b_ray / trace_s * 1e-9 if trace_s > 0 else 0.0
+        achieved = rays_kernel * b_ray / trace_s * 1e-9 if trace_s > 0 else 0.0
         out = {
             "metric": "Mrays/s", "value": rays_total / elapsed * 1e-6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -311,15 +316,17 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                 "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": rays_local * b_ray / max(launches[pta.TIMER_TRACE], 1),
+                "algorithmic_bytes_per_launch": rays_kernel * b_ray / max(launches[pta.TIMER_TRACE], 1),
                 "kernel": "trace_kernel (closest hit)", "bytes_per_ray": b_ray,
                 "box_tests_per_ray": n_box, "tri_tests_per_ray": n_tri, "hit_fraction": hit_frac,
                 "launches": launches[pta.TIMER_TRACE], "avg_launch_ms": ms[pta.TIMER_TRACE] / max(launches[pta.TIMER_TRACE], 1),
-                "rays_per_launch": rays_local / max(launches[pta.TIMER_TRACE], 1),
+                "rays_per_launch": rays_kernel / max(launches[pta.TIMER_TRACE], 1),
+                "rays_in_fused_tail_fraction": rays_tail / max(rays_local, 1.0),
             },
             "stage_ms_per_step": {
                 "raygen": ms[pta.TIMER_RAYGEN] / args.steps, "trace": ms[pta.TIMER_TRACE] / args.steps,
                 "shade": ms[pta.TIMER_SHADE] / args.steps, "accumulate": ms[pta.TIMER_ACCUM] / args.steps,
+                "fused_tail": ms[pta.TIMER_TAIL] / args.steps,
             },
             "max_queue": max_queue,
         }

@@ -63,10 +63,14 @@ enum {
                                * outgrows it adds nothing and is rendered again in halves at the next
                                * pt_synchronize / pt_download / pt_get_counters (PT_CNT_REPAIRED) */
     PT_OPT_LDS_NODES = 7,     /* tree nodes staged in LDS by the trace kernels (0 = none) */
-    PT_OPT_TRAVERSAL = 8      /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab quotients from
+    PT_OPT_TRAVERSAL = 8,     /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab quotients from
                                  the per-ray reciprocal plus one exact correction step instead of the division
                                  sequence (default on); bits 4..7: k of the node phase's early leave rule (default 4,
                                  0 = none); bit 2: refill a wave only when all its lanes are idle (measurement) */
+    PT_OPT_TAIL_LEVEL = 9     /* bounce levels from this one on are finished by one fused launch in which every
+                                 workgroup alternates trace and shade on its own queue region (default 6, the level
+                                 after Russian roulette starts, src/cs488.h:2153; 0 = one launch per level and stage).
+                                 Same device code either way, so the image does not depend on it */
 };
 
 /* Counter indices for pt_get_counters (all cumulative since pt_reset_counters). */
@@ -79,13 +83,15 @@ enum {
     PT_CNT_HITS = 5,        /* closest-hit queries that found a triangle */
     PT_CNT_MAX_QUEUE = 6,   /* largest ray-queue population seen */
     PT_CNT_REPAIRED = 7,    /* batches rendered again in halves after their ray queues overflowed */
-    PT_CNT_COUNT = 8
+    PT_CNT_TAIL_RAYS = 8,   /* the part of PT_CNT_RAYS traced by the fused launch of the deep levels */
+    PT_CNT_COUNT = 12
 };
 
 /* Timer indices for pt_get_timers (milliseconds / launches, cumulative; needs PT_OPT_PROFILE). */
 enum {
     PT_TIMER_RAYGEN = 0, PT_TIMER_TRACE = 1, PT_TIMER_SHADE = 2, PT_TIMER_ACCUM = 3,
-    PT_TIMER_COUNT = 4
+    PT_TIMER_TAIL = 4,      /* the fused launch of the deep levels (trace and shade together) */
+    PT_TIMER_COUNT = 5
 };
 
 /* pt_create(PT_DEVICE_NONE, ...) makes a context that never touches a GPU: it can load scenes and

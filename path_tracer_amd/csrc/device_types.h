@@ -104,7 +104,7 @@ enum { TRACE_STACK = 64 };
 // Device counters (uint64 each).  `totals` holds one set (DC_COUNT words) written by the tally and
 // accumulate kernels; `block_stats` holds DC_BLOCK_COUNT words per workgroup, each updated only by
 // its own workgroup with plain loads and stores, and is summed on the host.
-enum { DC_RAYS = 0, DC_NAN = 1, DC_OVERFLOW = 2, DC_MAXQ = 3, DC_COUNT = 4 };
+enum { DC_RAYS = 0, DC_NAN = 1, DC_TAIL_RAYS = 2, DC_MAXQ = 3, DC_COUNT = 4 };
 enum { DB_HITS = 0, DB_BOX = 1, DB_TRI = 2, DB_OVERFLOW = 3, DC_BLOCK_COUNT = 4 };
 
 struct LaunchCfg {
@@ -122,11 +122,14 @@ hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int
                         int grid_blocks, int cap_block, unsigned long long* block_stats);
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
-                        int* qcount_out, unsigned long long* block_stats);
+                        int* qcount_out);
+hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int kd, int mode, int level0, int levels,
+                       int max_level, QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount,
+                       unsigned long long* block_stats);
 hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const float4* sample_rad, float* accum,
                              unsigned long long* totals);
 // sums the per-workgroup queue counts of every level of a finished batch into totals
-hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, unsigned long long* totals);
+hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, int tail_level, unsigned long long* totals);
 hipError_t launch_resolve(const LaunchCfg& cfg, const float* accum, float* frame, int n_pixels, int total_samples);
 hipError_t launch_clear(const LaunchCfg& cfg, float* buf, size_t n);
 // unpacks rays6 (n x 6 floats) into queue form for the batch-trace entry

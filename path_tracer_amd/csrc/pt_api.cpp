@@ -87,6 +87,7 @@ struct PtContext {
     size_t max_batch = (size_t)1 << 24;
     int queue_factor = 4;
     int lds_nodes_opt = 256;
+    int tail_level = 6;  // levels from here on run in the fused kernel; Russian roulette starts at level 5 (src/cs488.h:2153)
 
     // device scene
     DeviceBuffer<float4> d_nodes, d_isect, d_tri_pos, d_tri_nrm, d_mats;
@@ -113,8 +114,8 @@ struct PtContext {
     uint64_t samples_started = 0;
     std::vector<TimedSpan> spans;
     std::deque<hipEvent_t> event_pool;
-    double timer_ms[PT_TIMER_COUNT] = {0, 0, 0, 0};
-    uint64_t timer_launches[PT_TIMER_COUNT] = {0, 0, 0, 0};
+    double timer_ms[PT_TIMER_COUNT] = {};
+    uint64_t timer_launches[PT_TIMER_COUNT] = {};
 
     float* accum_ptr() { return ext_accum ? ext_accum : d_accum.ptr; }
 };
@@ -426,7 +427,11 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
         ScopedTimer tm(c, PT_TIMER_RAYGEN);
         PT_HIP(c, launch_raygen(cfg, cam, b, q[0], c->d_sample_rad.ptr, c->d_qcount.ptr));
     }
-    for (int level = 0; level < levels; level++) {
+    // the deep, sparsely populated levels run in one fused launch (not while tests are counted or
+    // the static refill is being measured: those are properties of the per-level kernels)
+    const bool fuse = c->tail_level > 0 && c->tail_level < levels && !c->count_tests && (c->traversal & 4) == 0;
+    const int split = fuse ? c->tail_level : levels;
+    for (int level = 0; level < split; level++) {
         const QueueSet& in = q[level & 1];
         const QueueSet& out = q[(level + 1) & 1];
         {
@@ -437,14 +442,18 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
         {
             ScopedTimer tm(c, PT_TIMER_SHADE);
             PT_HIP(c, launch_shade(cfg, c->scene, b, level, c->max_level, in, c->d_hit.ptr, out, c->d_sample_rad.ptr,
-                                   c->d_qcount.ptr + (size_t)level * nb, c->d_qcount.ptr + (size_t)(level + 1) * nb,
-                                   c->d_block_stats.ptr));
+                                   c->d_qcount.ptr + (size_t)level * nb, c->d_qcount.ptr + (size_t)(level + 1) * nb));
         }
+    }
+    if (fuse) {
+        ScopedTimer tm(c, PT_TIMER_TAIL);
+        PT_HIP(c, launch_tail(cfg, c->scene, b, c->accel == PT_ACCEL_KD, c->traversal, split, levels, c->max_level, q[0], q[1],
+                              c->d_hit.ptr, c->d_sample_rad.ptr, c->d_qcount.ptr, c->d_block_stats.ptr));
     }
     {
         ScopedTimer tm(c, PT_TIMER_ACCUM);
         PT_HIP(c, launch_accumulate(cfg, b, c->d_sample_rad.ptr, c->accum_ptr(), c->d_totals.ptr));
-        PT_HIP(c, launch_tally(cfg, c->d_qcount.ptr, levels, nb, c->d_totals.ptr));
+        PT_HIP(c, launch_tally(cfg, c->d_qcount.ptr, levels, nb, split, c->d_totals.ptr));
     }
     c->samples_started += (uint64_t)b.n_slots;
     c->issued.push_back(rec);
@@ -621,6 +630,9 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             c->scene.lds_nodes = c->lds_nodes_opt < c->scene.n_nodes ? c->lds_nodes_opt : c->scene.n_nodes;
             break;
         case PT_OPT_TRAVERSAL: c->traversal = (int)value; break;
+        case PT_OPT_TAIL_LEVEL:
+            if (value > 64) return fail(c, PT_ERR_INVALID_ARG, "tail level above 64");
+            c->tail_level = (int)value; break;
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
     return PT_OK;
@@ -637,6 +649,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
         case PT_OPT_QUEUE_FACTOR: *value = (uint64_t)c->queue_factor; break;
         case PT_OPT_LDS_NODES: *value = (uint64_t)c->lds_nodes_opt; break;
         case PT_OPT_TRAVERSAL: *value = (uint64_t)c->traversal; break;
+        case PT_OPT_TAIL_LEVEL: *value = (uint64_t)c->tail_level; break;
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
     return PT_OK;
@@ -963,6 +976,7 @@ int pt_get_counters(PtContext* c, uint64_t out[PT_CNT_COUNT]) {
     out[PT_CNT_HITS] = st[DB_HITS];
     out[PT_CNT_MAX_QUEUE] = d[DC_MAXQ];
     out[PT_CNT_REPAIRED] = c->repaired_batches;
+    out[PT_CNT_TAIL_RAYS] = d[DC_TAIL_RAYS];
     return PT_OK;
 }
 

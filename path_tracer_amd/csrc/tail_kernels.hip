@@ -1,0 +1,82 @@
+// tail_kernels.hip -- one launch that finishes the deep bounce levels of a batch (gfx950).
+//
+// A workgroup owns its region of the ray queues: it consumes what it produced one level earlier,
+// so nothing couples the workgroups between levels and a workgroup can run trace -> shade ->
+// trace -> ... for all remaining levels by itself, with workgroup barriers only.  From the level
+// at which Russian roulette has thinned the paths out (src/cs488.h:2153-2160), a launch per level
+// and stage costs more in launch gaps and nearly empty grids than the work itself; this kernel
+// replaces those launches.  It walks and shades with the same device code as the per-level
+// kernels (trace_device.h, shade_device.h), so results are identical.
+#include "shade_device.h"
+#include "trace_device.h"
+
+namespace pt {
+
+namespace {
+
+using namespace trace_dev;
+using namespace shade_dev;
+
+template <bool KD, int SLAB, bool ALL_LDS>
+__global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int level0, int levels, int max_level, QueueSet qa,
+                                                   QueueSet qb, float4* __restrict__ hit, float4* __restrict__ sample_rad,
+                                                   int* __restrict__ qcount, unsigned long long* __restrict__ block_stats,
+                                                   int leave_k) {
+    extern __shared__ float4 lds_nodes[];
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[4];
+    __shared__ __attribute__((aligned(16))) int s_stack[LDS_STACK * 256];
+    __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LDS_STACK * 256 : 4];
+    __shared__ int s_out;
+    const int blk = blockIdx.x;
+    const int nb = b.blocks;
+    int n = qcount[(size_t)level0 * nb + blk];
+    n = n < b.cap_block ? n : b.cap_block;
+    const size_t region = (size_t)blk * b.cap_block;
+    if (n > 0) stage_tree<ALL_LDS>(sc, lds_nodes);  // n is the same for every thread of the workgroup
+    TraceLds<KD> lds;
+    lds.nodes = lds_nodes; lds.stat = s_stat; lds.stack = s_stack; lds.stack_t = s_stack_t;
+    for (int level = level0; level < levels; level++) {
+        if (n > 0) {
+            const QueueSet& in = (level & 1) ? qb : qa;
+            const QueueSet& out = (level & 1) ? qa : qb;
+            trace_region<KD, false, SLAB, true, ALL_LDS>(sc, in.ray_o, in.ray_d, hit, n, region, block_stats, leave_k, lds);
+            n = shade_region(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
+            __syncthreads();  // s_out is rewritten by the next level's shading
+        }
+        if (threadIdx.x == 0) qcount[(size_t)(level + 1) * nb + blk] = n;  // the tally reads every level
+    }
+}
+
+template <bool KD, int SLAB>
+void launch_tail_variant(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level0, int levels, int max_level,
+                         QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount, unsigned long long* block_stats,
+                         int leave_k) {
+    const size_t lds = (size_t)scene.lds_nodes * 64;
+    if (scene.lds_nodes >= scene.n_nodes && scene.leaf_inline && scene.n_records <= LDS_RECORDS_MAX)
+        hipLaunchKernelGGL((tail_kernel<KD, SLAB, true>), dim3(batch.blocks), dim3(256), lds + (size_t)scene.n_records * 64, cfg.stream,
+                           scene, batch, level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k);
+    else
+        hipLaunchKernelGGL((tail_kernel<KD, SLAB, false>), dim3(batch.blocks), dim3(256), lds, cfg.stream, scene, batch, level0,
+                           levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k);
+}
+
+}  // namespace
+
+// Runs levels [level0, levels) of the batch; qa is the queue set that even levels read.  `mode`
+// as in launch_trace (the tail always refills dynamically and never counts tests).
+hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int kd, int mode, int level0, int levels,
+                       int max_level, QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount,
+                       unsigned long long* block_stats) {
+    const bool recip = (mode & 1) != 0;
+    const int leave_k = (mode >> 4) & 15;
+#define PT_ARGS cfg, scene, batch, level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k
+    if (kd) {
+        if (recip) launch_tail_variant<true, SLAB_RECIP>(PT_ARGS); else launch_tail_variant<true, SLAB_DIVIDE>(PT_ARGS);
+    } else {
+        if (recip) launch_tail_variant<false, SLAB_RECIP>(PT_ARGS); else launch_tail_variant<false, SLAB_DIVIDE>(PT_ARGS);
+    }
+#undef PT_ARGS
+    return hipGetLastError();
+}
+
+}  // namespace pt

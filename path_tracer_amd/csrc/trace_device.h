@@ -1,0 +1,383 @@
+// trace_device.h -- device code of the closest-hit stage (gfx950), shared by the per-level trace
+// kernel and the fused kernel that finishes the deep bounce levels.
+//
+// One lane walks one ray through the flattened BVH or kd-tree and keeps the nearest triangle.
+// The walk reproduces the reference's recursion exactly, so that the winning triangle and its
+// distance are the reference's own:
+//   * slab test per child with true divisions, NaN-transparent comparisons and the entry
+//     distance as result (AABB::intersect, src/cs488.h:530-567);
+//   * a child is entered only if its entry distance is below the best hit so far; with both
+//     children eligible the one with the smaller entry distance goes first and on a tie the
+//     RIGHT one (src/cs488.h:1687-1697, 1360-1370);
+//   * BVH: the deferred child is entered unconditionally (src/cs488.h:1692-1696);
+//     kd-tree: it is entered only if its entry distance is still below the best hit
+//     (src/cs488.h:1366,1369);
+//   * a leaf tests its triangles in stored order and a hit replaces the best only when strictly
+//     nearer (src/cs488.h:1677-1681, 1350-1354);
+//   * the triangle test is the Cramer's-rule form with inclusive barycentric and distance
+//     bounds (TriangleMesh::raytraceTriangle, src/cs488.h:646-681).
+// This file is compiled with -ffp-contract=off: the x86 reference evaluates every product and
+// sum separately, and a fused multiply-add here would change low-order bits of t.
+//
+// Launch shape: one 256-lane workgroup per queue region; the region's length is read from device
+// memory (written by the previous stage), so the host never waits for a count.  A wave alternates
+// two tight loops: the node phase, in which every lane standing on an interior node takes steps
+// (two slab tests, push, descend or pop) while the other lanes wait, and the leaf phase, in which
+// every lane standing on a leaf tests up to four of its triangles.  The node phase is left when
+// none of its lanes remain or when they are outnumbered k to 1 by the lanes waiting at a leaf, so
+// neither code path runs nearly empty because of one long walk or one large leaf.  Lanes whose ray
+// is finished take the next rays of the region through an LDS counter (one atomic per refill) as
+// soon as a quarter of the wave is idle.  The first `lds_nodes` tree nodes (the top levels; nodes are numbered breadth-first) are
+// copied into LDS by every workgroup that has work; the first LDS_STACK entries of every lane's
+// traversal stack live in LDS as well.
+#pragma once
+
+#include <float.h>
+#include <limits.h>
+
+#include "device_math.h"
+#include "device_types.h"
+#include "pt_math.h"
+
+namespace pt {
+
+namespace trace_dev {
+
+
+__device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                          vec3 o, vec3 d, float& t_entry) {
+    float tx1 = (lox - o.x) / d.x, ty1 = (loy - o.y) / d.y, tz1 = (loz - o.z) / d.z;
+    float tx2 = (hix - o.x) / d.x, ty2 = (hiy - o.y) / d.y, tz2 = (hiz - o.z) / d.z;
+    if (tx1 > tx2) { float s = tx1; tx1 = tx2; tx2 = s; }
+    if (ty1 > ty2) { float s = ty1; ty1 = ty2; ty2 = s; }
+    if (tz1 > tz2) { float s = tz1; tz1 = tz2; tz2 = s; }
+    float t1 = tx1; if (t1 < ty1) t1 = ty1; if (t1 < tz1) t1 = tz1;
+    float t2 = tx2; if (t2 > ty2) t2 = ty2; if (t2 > tz2) t2 = tz2;
+    t_entry = t1;
+    if (t1 > t2) return false;
+    if ((t1 < 0.0f) && (t2 < 0.0f)) return false;
+    return true;
+}
+
+struct Best {
+    float t, beta, gamma;
+    int tri;
+};
+
+// TriangleMesh::raytraceTriangle (src/cs488.h:646-681) on an intersection record: the edge vectors
+// a, b and cross(a, b) come precomputed (they do not depend on the ray), the rest is evaluated here
+// in the reference's order.  The three quotients by the determinant are true divisions in the
+// reference; FAST_DIV forms them from the exact reciprocal whenever the determinant and the three
+// numerators are in a range in which no intermediate overflows or becomes subnormal (a zero
+// numerator is left to the division so that the sign of a zero quotient is the reference's).
+template <bool FAST_DIV>
+__device__ __forceinline__ void triangle_test(const float4& r0, const float4& r1, const float4& r2, const float4& r3,
+                                              vec3 o, vec3 d, Best& best) {
+    const vec3 a = v3(r1.x, r1.y, r1.z);
+    const vec3 b = v3(r2.x, r2.y, r2.z);
+    const vec3 ab = v3(r3.x, r3.y, r3.z);
+    const vec3 e = v3(r0.x, r0.y, r0.z) - o;
+    const float D = dot(ab, d);
+    if (D != 0) {
+        const float Da = dot(cross(e, b), d);
+        const float Db = dot(cross(a, e), d);
+        const float Dc = dot(ab, e);
+        float beta, gamma, t;
+        const float lo = fminf(fminf(fabsf(Da), fabsf(Db)), fabsf(Dc));
+        const float hi = fmaxf(fmaxf(fabsf(Da), fabsf(Db)), fabsf(Dc));
+        if (FAST_DIV && lo >= 1e-22f && hi <= 1e15f && fabsf(D) >= 1e-15f && fabsf(D) <= 1e15f) {
+            const float r = exact_reciprocal(D);
+            beta = div_by_recip(Da, D, r);
+            gamma = div_by_recip(Db, D, r);
+            t = div_by_recip(Dc, D, r);
+        } else {
+            beta = Da / D;
+            gamma = Db / D;
+            t = Dc / D;
+        }
+        const float alpha = 1 - beta - gamma;
+        if (0 <= alpha && alpha <= 1 && 0 <= beta && beta <= 1 && 0 <= gamma && gamma <= 1 && 0.0f <= t && t <= FLT_MAX) {
+            if (t < best.t) { best.t = t; best.beta = beta; best.gamma = gamma; best.tri = __float_as_int(r0.w); }
+        }
+    }
+}
+
+// ---- slab test without the division sequence ---------------------------------------------------
+// SLAB_DIVIDE: the division form above, always.
+// SLAB_RECIP:  every quotient (plane - origin) / direction is formed from the per-ray reciprocal
+//   r = RN(1 / d) as  q0 = RN(a r);  e = RN(fma(-q0, d, a));  q = RN(fma(e, r, q0)).
+//   The residual e is exact and the corrected q equals RN(a / d) for EVERY pair of binary32
+//   significands -- checked exhaustively (2^46 pairs, tools/verify_recip_division.hip) -- hence for
+//   all operands as long as nothing overflows or becomes subnormal.  Rays for which that cannot be
+//   promised from their origin and direction alone (`recip_ok` below) use the division form, so both
+//   settings give bit-identical entry distances and therefore the identical walk.
+enum { SLAB_DIVIDE = 0, SLAB_RECIP = 1 };
+
+// Only called for rays that passed recip_ok: all six quotients are finite, so the reference's
+// swap / running-max / running-min sequence (src/cs488.h:541-560) reduces to plain min and max
+// (the sign of a zero may differ, which no comparison below or in the walk can see).
+__device__ __forceinline__ bool slab_test_recip(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                                vec3 o, vec3 d, vec3 r, float& t_entry) {
+    const float tx1 = div_by_recip(lox - o.x, d.x, r.x), ty1 = div_by_recip(loy - o.y, d.y, r.y), tz1 = div_by_recip(loz - o.z, d.z, r.z);
+    const float tx2 = div_by_recip(hix - o.x, d.x, r.x), ty2 = div_by_recip(hiy - o.y, d.y, r.y), tz2 = div_by_recip(hiz - o.z, d.z, r.z);
+    const float t1 = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fminf(tz1, tz2));
+    const float t2 = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fmaxf(tz1, tz2));
+    t_entry = t1;
+    return !(t1 > t2) && !((t1 < 0.0f) && (t2 < 0.0f));
+}
+
+// May the reciprocal form be used for this ray?  Needs, per axis: a finite direction component
+// with 1e-10 <= |d| <= 1e10 (so r and every quotient stay normal), an origin coordinate that is 0
+// or at least 1e-17 in magnitude (with the same property of the box planes, checked on the host,
+// a non-zero plane - origin is then at least 1e-25 and its quotient and residual stay normal), and
+// |plane - origin| < 1e15 for every plane inside the root box.
+__device__ __forceinline__ bool recip_ok(vec3 o, vec3 d, vec3 rlo, vec3 rhi) {
+    const float dmax = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float dmin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+    const float reach = fmaxf(fmaxf(fmaxf(fabsf(rlo.x - o.x), fabsf(rhi.x - o.x)), fmaxf(fabsf(rlo.y - o.y), fabsf(rhi.y - o.y))),
+                              fmaxf(fabsf(rlo.z - o.z), fabsf(rhi.z - o.z)));
+    const bool ox = o.x == 0.0f || fabsf(o.x) >= 1e-17f, oy = o.y == 0.0f || fabsf(o.y) >= 1e-17f, oz = o.z == 0.0f || fabsf(o.z) >= 1e-17f;
+    return (dmax <= 1e10f) && (dmin >= 1e-10f) && (reach < 1e15f) && ox && oy && oz;  // NaNs fail the comparisons
+}
+
+// What one visit of an interior node decides.
+struct NodeStep {
+    int next;          // child to enter now (valid if descend)
+    int deferred;      // child to push (valid if push)
+    float deferred_t;  // its entry distance (kd-tree only)
+    bool descend, push;
+};
+
+// The reference's decisions for one interior node (src/cs488.h:1684-1701, 1357-1375).
+template <bool RECIP>
+__device__ __forceinline__ void node_step(const float4& q0, const float4& q1, const float4& q2, const float4& q3,
+                                          vec3 o, vec3 d, vec3 r, float best_t, NodeStep& st) {
+    float tl, tr;
+    bool hl, hr;
+    if (RECIP) {
+        hl = slab_test_recip(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, r, tl);
+        hr = slab_test_recip(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, r, tr);
+    } else {
+        hl = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tl);
+        hr = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tr);
+    }
+    hl = hl && (tl < best_t);
+    hr = hr && (tr < best_t);
+    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+    st.push = hl && hr;
+    st.descend = hl || hr;
+    const bool left_first = hl && (!hr || (tl < tr));  // both: nearer first, right on ties; one: that one
+    st.next = left_first ? left : right;
+    st.deferred = left_first ? right : left;
+    st.deferred_t = left_first ? tr : tl;
+}
+
+// The first LDS_STACK entries of a lane's traversal stack live in LDS (entry e of lane t at
+// [e * 256 + t]: consecutive lanes on consecutive banks), deeper ones in the lane's scratch array.
+enum { LDS_STACK = 12 };
+// Triangles a lane tests per visit of the leaf phase.
+enum { LEAF_BURST = 4 };
+
+// A lane's `cur`: >= 0 interior node, < 0 leaf (~offset of its first record), NO_RAY = no ray.
+enum : int { NO_RAY = INT_MIN };
+
+// ALL_LDS: every interior node and every (leaf-ordered) intersection record is staged in LDS --
+// small scenes -- so neither the walk nor the leaf phase has a global-memory path.
+enum { LDS_RECORDS_MAX = 256 };
+// LDS a workgroup needs for the walk: the staged nodes (and records), four counters, the stacks.
+template <bool KD>
+struct TraceLds {
+    float4* nodes;          // dynamic LDS: lds_nodes node records, then (ALL_LDS) the leaf records
+    unsigned int* stat;     // 4: hits, slab tests, triangle tests, next ray of the region
+    int* stack;             // LDS_STACK * 256
+    float* stack_t;         // LDS_STACK * 256 (kd-tree only)
+};
+
+// Copies the top of the tree (and, with ALL_LDS, the leaf records) into LDS; every thread of the
+// workgroup calls it, a barrier must follow before the first walk.
+template <bool ALL_LDS>
+__device__ __forceinline__ void stage_tree(const SceneGpu& sc, float4* lds_nodes) {
+    const int staged = sc.lds_nodes;
+    for (int k = threadIdx.x; k < staged * 4; k += blockDim.x) lds_nodes[k] = sc.nodes[k];
+    float4* lds_records = lds_nodes + 4 * staged;
+    if (ALL_LDS)
+        for (int k = threadIdx.x; k < sc.n_records * 4; k += blockDim.x) lds_records[k] = sc.isect[k];
+}
+
+// Closest hits for the n rays at [region, region + n) of the queue; called by all 256 threads of
+// the workgroup with the tree already staged.  Ends with the workgroup's hit records written and
+// a barrier passed.
+template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS>
+__device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* __restrict__ ray_o,
+                                             const float4* __restrict__ ray_d, float4* __restrict__ hit, int n, size_t region,
+                                             unsigned long long* __restrict__ block_stats, int leave_k, const TraceLds<KD>& lds) {
+    float4* const lds_nodes = lds.nodes;
+    unsigned int* const s_stat = lds.stat;
+    int* const s_stack = lds.stack;
+    float* const s_stack_t = lds.stack_t;
+    const int blk = blockIdx.x;
+    const int staged = sc.lds_nodes;
+    float4* const lds_records = lds_nodes + 4 * staged;
+    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    __syncthreads();
+
+    const vec3 rlo = v3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]);
+    const vec3 rhi = v3(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2]);
+    unsigned int n_box = 0, n_tri = 0, n_hit = 0;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    // per-lane state of the ray in progress
+    vec3 o = v3(0.0f), d = v3(0.0f), inv = v3(0.0f);
+    Best best;
+    best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+    int deep[TRACE_STACK - LDS_STACK];
+    float deep_t[KD ? TRACE_STACK - LDS_STACK : 1];
+    int sp = 0, cur = NO_RAY;
+    int leaf_k = 0, leaf_n = 0;  // next triangle of the leaf the lane stands on, and the leaf's size
+    size_t slot = 0;
+    bool fast_ok = false;
+    bool drained = false;  // wave-uniform: the region has no unassigned ray left
+    const int refill_min = DYNAMIC ? 16 : 64;
+
+    // Takes the next deferred child; when none is left the ray is finished and its record written.
+    auto pop_or_finish = [&]() {
+        while (sp > 0) {
+            sp--;
+            // the LDS read is unconditional (clamped) and the rare deep entry overrides it, which
+            // keeps the common case a plain LDS load instead of a load through a generic pointer
+            const int e = sp < LDS_STACK ? sp : LDS_STACK - 1;
+            int ref = s_stack[e * 256 + tid];
+            float t_ref = 0.0f;
+            if (KD) t_ref = s_stack_t[e * 256 + tid];
+            asm volatile("" : "+v"(ref), "+v"(t_ref));  // keeps the two loads from being merged into one generic load
+            if (__builtin_expect(sp >= LDS_STACK, 0)) {
+                ref = deep[sp - LDS_STACK];
+                if (KD) t_ref = deep_t[sp - LDS_STACK];
+            }
+            if (KD && !(t_ref < best.t)) continue;
+            cur = ref;
+            return;
+        }
+        if (best.tri >= 0) n_hit++;
+        hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.beta, best.gamma);
+        cur = NO_RAY;
+    };
+
+    while (true) {
+        // ---- idle lanes take the next rays of the region, once enough of them are idle ----
+        const unsigned long long idle = __ballot(cur == NO_RAY);
+        const int n_idle = __popcll(idle);
+        if (n_idle == 64 && drained) break;
+        if (!drained && n_idle >= refill_min) {
+            int base = 0;
+            if (lane == 0) base = (int)atomicAdd(&s_stat[3], (unsigned int)n_idle);
+            base = __shfl(base, 0);
+            drained = base + n_idle >= n;
+            const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
+            if (cur == NO_RAY && j < n) {
+                slot = region + j;
+                const float4 ro = ray_o[slot], rd = ray_d[slot];
+                o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
+                best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+                sp = 0;
+                if (SLAB == SLAB_RECIP) {
+                    fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
+                    if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
+                }
+                float t_root;
+                if (COUNT) n_box++;
+                const bool in_root = (SLAB == SLAB_RECIP && fast_ok) ? slab_test_recip(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, inv, t_root)
+                                                                     : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
+                if (in_root) {  // src/cs488.h:1438, 1405
+                    cur = sc.root_ref;
+                    leaf_k = 0;
+                } else {
+                    hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
+                }
+            }
+        }
+
+        // ---- node phase: lanes on interior nodes walk until too few of them are left ----
+        // (leave when nobody walks, or when the walkers are fewer than 1/k of the lanes waiting at a leaf)
+        while (true) {
+            const int walking = __popcll(__ballot(cur >= 0));
+            if (walking == 0) break;
+            if (leave_k > 0 && walking * leave_k < __popcll(__ballot((unsigned int)cur > (unsigned int)NO_RAY))) break;
+            if (cur >= 0) {
+                float4 q0, q1, q2, q3;
+                if (ALL_LDS || cur < staged) {
+                    q0 = lds_nodes[4 * cur]; q1 = lds_nodes[4 * cur + 1]; q2 = lds_nodes[4 * cur + 2]; q3 = lds_nodes[4 * cur + 3];
+                } else {
+                    const float4* np = sc.nodes + 4 * (size_t)cur;
+                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+                }
+                if (COUNT) n_box += 2;
+                NodeStep st;
+                if (SLAB == SLAB_RECIP && fast_ok) node_step<true>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                else node_step<false>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                if (st.push) {
+                    if (__builtin_expect(sp < LDS_STACK, 1)) {
+                        s_stack[sp * 256 + tid] = st.deferred;
+                        if (KD) s_stack_t[sp * 256 + tid] = st.deferred_t;
+                    } else {
+                        deep[sp - LDS_STACK] = st.deferred;
+                        if (KD) deep_t[sp - LDS_STACK] = st.deferred_t;
+                    }
+                    sp++;
+                }
+                if (st.descend) cur = st.next; else pop_or_finish();
+                leaf_k = 0;
+            }
+        }
+
+        // ---- leaf phase: every lane on a leaf tests up to LEAF_BURST of its triangles, in stored
+        // order (src/cs488.h:1677-1681, 1350-1354); a larger leaf is finished in the next round, so
+        // one big leaf does not hold the other lanes
+        if ((unsigned int)cur > (unsigned int)NO_RAY) {
+            const int off = ~cur;
+            if (KD && !sc.leaf_inline) {
+                if (leaf_k == 0) leaf_n = sc.refs[off];
+                const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
+                for (; leaf_k < stop; leaf_k++) {
+                    if (COUNT) n_tri++;
+                    const float4* rec = sc.isect + 4 * (size_t)sc.refs[off + 1 + leaf_k];
+                    triangle_test<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, best);
+                }
+            } else {
+                const float4* rec = ALL_LDS ? lds_records + 4 * (off + leaf_k) : sc.isect + 4 * (size_t)(off + leaf_k);
+                float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                if (leaf_k == 0) leaf_n = __float_as_int(r1.w);
+                const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
+                for (; leaf_k < stop; leaf_k++) {
+                    if (COUNT) n_tri++;
+                    triangle_test<SLAB == SLAB_RECIP>(r0, r1, r2, r3, o, d, best);
+                    if (leaf_k + 1 < stop) { rec += 4; r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+                }
+            }
+            if (leaf_k >= leaf_n) { pop_or_finish(); leaf_k = 0; }
+        }
+    }
+
+    // statistics: wave sums -> LDS -> this workgroup's own slots (no global atomics)
+    unsigned int tot_hit = n_hit, tot_box = n_box, tot_tri = n_tri;
+    for (int off = 32; off > 0; off >>= 1) {
+        tot_hit += __shfl_down(tot_hit, off);
+        if (COUNT) { tot_box += __shfl_down(tot_box, off); tot_tri += __shfl_down(tot_tri, off); }
+    }
+    if (lane == 0) {
+        atomicAdd(&s_stat[0], tot_hit);
+        if (COUNT) { atomicAdd(&s_stat[1], tot_box); atomicAdd(&s_stat[2], tot_tri); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* st = block_stats + (size_t)blk * DC_BLOCK_COUNT;
+        st[DB_HITS] += s_stat[0];
+        if (COUNT) { st[DB_BOX] += s_stat[1]; st[DB_TRI] += s_stat[2]; }
+    }
+}
+
+
+}  // namespace trace_dev
+
+}  // namespace pt

@@ -187,3 +187,29 @@ def test_overflowing_batches_are_rendered_again(gpu_device):
     o.render(spp=16, frames=1, threads=8)
     ref = o.image()
     assert abs(big.mean() / 16 - ref.mean()) < 0.03 * ref.mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obj,accel", [("cornellbox.obj", pta.BVH), ("cornellbox-alpha.obj", pta.KD), ("teapot.obj", pta.BVH)])
+def test_fused_tail_gives_the_per_level_image(gpu_device, obj, accel):
+    """The fused launch of the deep levels runs the same device code on the same queue regions as
+    the per-level launches: same ray count, same image (bit for bit where no two paths share a
+    sample; forked paths add to one sample with float atomics, whose order is free)."""
+    def render(tail):
+        s = load_gpu_scene(obj, accel, env="probe_64.hdr" if obj.startswith("teapot") else None)
+        s.set_option(pta.OPT_TAIL_LEVEL, tail)
+        s.set_resolution(96, 72)
+        s.pathtrace(16)
+        return s.accumulation_buffer(), s.counters()
+
+    ref, c_ref = render(0)
+    assert c_ref[pta.CNT_TAIL_RAYS] == 0
+    for tail in (6, 2, 1):
+        img, c = render(tail)
+        assert c[pta.CNT_RAYS] == c_ref[pta.CNT_RAYS]
+        assert c[pta.CNT_HITS] == c_ref[pta.CNT_HITS]
+        assert 0 < c[pta.CNT_TAIL_RAYS] < c[pta.CNT_RAYS] or obj.startswith("teapot")
+        if "alpha" in obj:
+            assert np.allclose(img, ref, rtol=1e-5, atol=1e-6)
+        else:
+            assert np.array_equal(img, ref)
