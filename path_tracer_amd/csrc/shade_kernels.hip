@@ -91,12 +91,20 @@ __global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float
         float* dst = accum + 3 * (size_t)(b.pixel0 + pl);
         float ax = dst[0], ay = dst[1], az = dst[2];
         const float4* src = sample_rad + (size_t)pl * b.chunk;
-        for (int k = 0; k < b.chunk; k++) {
-            const float4 s = src[k];
-            if (isnan(s.x) || isnan(s.y) || isnan(s.z)) {
-                dropped++;
-            } else {
-                ax += s.x; ay += s.y; az += s.z;
+        // four loads in flight per lane (one 64-byte sector), summed in sample order
+        for (int k0 = 0; k0 < b.chunk; k0 += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = k0 + u < b.chunk ? src[k0 + u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (k0 + u >= b.chunk) break;
+                const float4 s = v[u];
+                if (isnan(s.x) || isnan(s.y) || isnan(s.z)) {
+                    dropped++;
+                } else {
+                    ax += s.x; ay += s.y; az += s.z;
+                }
             }
         }
         dst[0] = ax; dst[1] = ay; dst[2] = az;
