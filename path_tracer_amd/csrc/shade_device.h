@@ -244,7 +244,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
         int slot = 0;
 
         if (j < n) {
-            const float4 ro = in.ray_o[i], rd = in.ray_d[i], bt = in.beta[i], h = hit[i];
+            const float4 rd = in.ray_d[i], bt = in.beta[i], h = hit[i];
             const vec3 d = v3(rd.x, rd.y, rd.z);
             const vec3 beta = v3(bt.x, bt.y, bt.z);
             slot = __float_as_int(bt.w);
@@ -254,7 +254,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
 
             if (tri < 0) {
                 // miss: environment radiance (zero without a probe; the product keeps a NaN alive)
-                const vec3 e = env_lookup(sc, d) * ro.w;
+                const vec3 e = env_lookup(sc, d) * h.z;  // miss record: h.z = the ray's miss scale
                 if (sc.env_h != 0 || !finite3(beta)) add_radiance(sample_rad, slot, beta * e);
             } else if (level > max_level) {
                 ended = true;

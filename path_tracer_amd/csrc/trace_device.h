@@ -236,6 +236,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     int sp = 0, cur = NO_RAY;
     int leaf_k = 0, leaf_n = 0;  // next triangle of the leaf the lane stands on, and the leaf's size
     size_t slot = 0;
+    float miss_scale = 1.0f;  // the ray's factor on the environment radiance (ray_o.w), handed on in a miss record
     bool fast_ok = false;
     bool drained = false;  // wave-uniform: the region has no unassigned ray left
     const int refill_min = DYNAMIC ? 16 : 64;
@@ -260,7 +261,9 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             return;
         }
         if (best.tri >= 0) n_hit++;
-        hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.beta, best.gamma);
+        // a miss carries the ray's miss scale where a hit has beta, so the shading stage reads one
+        // record per path instead of the ray's origin as well
+        hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.tri >= 0 ? best.beta : miss_scale, best.gamma);
         cur = NO_RAY;
     };
 
@@ -279,6 +282,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 slot = region + j;
                 const float4 ro = ray_o[slot], rd = ray_d[slot];
                 o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
+                miss_scale = ro.w;
                 best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
                 sp = 0;
                 if (SLAB == SLAB_RECIP) {
@@ -293,7 +297,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     cur = sc.root_ref;
                     leaf_k = 0;
                 } else {
-                    hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, 0.0f, 0.0f);
+                    hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, ro.w, 0.0f);
                 }
             }
         }

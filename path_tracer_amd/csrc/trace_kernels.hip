@@ -50,7 +50,8 @@ __global__ void unpack_hits_kernel(const float4* __restrict__ hit, int n, int* t
         const float4 h = hit[i];
         tri[i] = __float_as_int(h.x);
         t[i] = h.y;
-        if (bary2) { bary2[2 * i] = h.z; bary2[2 * i + 1] = h.w; }
+        const bool found = __float_as_int(h.x) >= 0;  // a miss record holds the ray's miss scale in place of beta
+        if (bary2) { bary2[2 * i] = found ? h.z : 0.0f; bary2[2 * i + 1] = found ? h.w : 0.0f; }
     }
 }
 
