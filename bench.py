@@ -88,6 +88,22 @@ def measured_traffic(args, world):
     return (k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json") if k else (None, None)
 
 
+def measured_valu(args, world):
+    """VALU side of trace_kernel from the committed SQ counter passes (tools/pmc_valu.py): share of
+    the chip's VALU issue slots in use and lanes active per VALU instruction.  Same restriction as
+    measured_traffic: only for the workload the passes ran."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
+    is_default = (args.workload == "cornellbox" and not args.obj and args.accel == "bvh" and
+                  (args.width, args.height, args.spp) == (1024, 1024, 10) and world == 1)
+    if not is_default or not os.path.exists(path):
+        return None
+    k = json.load(open(path))["kernels"].get("trace_kernel")
+    if not k:
+        return None
+    return {"issue_busy": k.get("valu_issue_busy"), "lane_occupancy": k.get("valu_lane_occupancy"),
+            "wave_instructions_per_launch": k["per_launch"].get("SQ_INSTS_VALU"), "source": "profiles/r01_pmc_valu.json"}
+
+
 def bytes_per_ray(n_box, n_tri, hit_frac, textured=False):
     """Algorithmic bytes one closest-hit query moves: 24 B per slab test (6 floats), 36 B per
     triangle test (9 floats), 48 B of normals + material id for a winning hit, 160 B of wavefront
@@ -322,6 +338,7 @@ def main():
                 "launches": launches[pta.TIMER_TRACE], "avg_launch_ms": ms[pta.TIMER_TRACE] / max(launches[pta.TIMER_TRACE], 1),
                 "rays_per_launch": rays_kernel / max(launches[pta.TIMER_TRACE], 1),
                 "rays_in_fused_tail_fraction": rays_tail / max(rays_local, 1.0),
+                "valu": measured_valu(args, world),
             },
             "stage_ms_per_step": {
                 "raygen": ms[pta.TIMER_RAYGEN] / args.steps, "trace": ms[pta.TIMER_TRACE] / args.steps,

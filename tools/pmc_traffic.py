@@ -21,7 +21,8 @@ def collect(d, counter):
                 continue
             k = r["Kernel_Name"]
             k = "trace_kernel" if "trace_kernel" in k else "shade_kernel" if "shade_kernel" in k else \
-                "raygen_kernel" if "raygen" in k else "accumulate_kernel" if "accumulate" in k else None
+                "raygen_kernel" if "raygen" in k else "accumulate_kernel" if "accumulate" in k else \
+                "tail_kernel" if "tail_kernel" in k else None
             if k:
                 tot[k] += float(r["Counter_Value"])
                 n[k].add(r["Dispatch_Id"])

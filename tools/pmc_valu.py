@@ -19,7 +19,7 @@ SIMDS = 256 * 4
 
 
 def short(k):
-    for n in ("trace_kernel", "shade_kernel", "raygen_kernel", "accumulate_kernel"):
+    for n in ("trace_kernel", "shade_kernel", "raygen_kernel", "accumulate_kernel", "tail_kernel"):
         if n in k:
             return n
     return None
