@@ -15,8 +15,21 @@
 //   --eye/--lookat/--up x y z, --fov deg   camera globals         (src/cs488.h:75,83-85)
 // Headless additions: --frames N (default 10), --out file.png|.pfm (the `I` key's
 // FrameBuffer.save, src/cs488.h:249-253), --seed N, --device N, --stats (ray statistics and
-// Mrays/s on stderr after the last frame).
+// Mrays/s on stderr after the last frame), --sequence PREFIX (every frame to PREFIX%04d.png).
+//
+// Window input is replaced by a script (--script FILE), one event per line, applied where the
+// reference polls events, i.e. before the frame with that index is rendered (src/cs488.h:2283):
+//   <frame> key W|S|A|D|Q|Z      move eye and lookat by SCLFACT along view / right / up (src/cs488.h:270-298)
+//   <frame> key I                save the frame buffer as output<n>.png, n = int(1000 rand()) (:249-253)
+//   <frame> key F                start / stop recording (:255-268); recorded frames go to
+//                                output<n>_%04d.png instead of an animated .gif
+//   <frame> key ESCAPE           leave the loop (:245-247)
+//   <frame> drag <dx> <dy>       cursor movement in pixels with the left button held (:317-344)
+//   <frame> save <file>          write the frame buffer (.png or .pfm)
+// As in the reference, accumulation restarts only when the view direction or the right vector
+// changed (src/cs488.h:2266-2293): translations keep accumulating.
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,14 +49,73 @@ struct Options {
     uint64_t seed = 0;
     float eye[3] = {0.0f, 0.0f, 1.5f}, lookat[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
     float fov = 45.0f;
-    std::string out;
+    std::string out, script, sequence;
 };
+
+struct Event {
+    int frame;
+    std::string kind, arg;  // key <name> | drag | save <file>
+    float dx = 0.0f, dy = 0.0f;
+};
+
+// float3 arithmetic of the input callbacks (src/cs488.h:270-341), component-wise like linalg.h
+struct F3 { float x, y, z; };
+F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+F3 operator*(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
+float dot(F3 a, F3 b) { return ((0.0f + a.x * b.x) + a.y * b.y) + a.z * b.z; }
+F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+F3 normalize(F3 a) { const float l = sqrtf(dot(a, a)); return {a.x / l, a.y / l, a.z / l}; }
+bool differs(F3 a, F3 b) { return a.x != b.x || a.y != b.y || a.z != b.z; }
+
+// rotateVector of cursorPosFunc (src/cs488.h:324-335)
+F3 rotate_about(float theta, F3 v, F3 w) {
+    const float c = cosf(theta), s = sinf(theta);
+    const F3 v0 = dot(v, w) * w;
+    const F3 v1 = v - v0;
+    const F3 v2 = cross(w, v1);
+    return v0 + c * v1 + s * v2;
+}
+
+// PCG32::rand (src/cs488.h:130-143): names of the files the I and F keys write, one draw per frame (:2317)
+struct Pcg32 {
+    uint64_t state = 0xcafef00dd15ea5e5ull;
+    float rand() {
+        uint64_t x = state;
+        const unsigned count = (unsigned)(x >> 61);
+        state = x * 6364136223846793005ull;
+        x ^= x >> 22;
+        return (float)((double)(uint32_t)(x >> (22 + count)) / 4294967296.0);
+    }
+};
+
+bool read_script(const std::string& path, std::vector<Event>& out) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char line[512];
+    while (fgets(line, sizeof(line), f)) {
+        char kind[32] = "", arg[256] = "";
+        Event e;
+        if (line[0] == '#' || sscanf(line, "%d %31s", &e.frame, kind) != 2) continue;
+        e.kind = kind;
+        if (e.kind == "drag") {
+            if (sscanf(line, "%*d %*s %f %f", &e.dx, &e.dy) != 2) { fclose(f); return false; }
+        } else if (e.kind == "key" || e.kind == "save") {
+            if (sscanf(line, "%*d %*s %255s", arg) != 1) { fclose(f); return false; }
+            e.arg = arg;
+        } else { fclose(f); return false; }
+        out.push_back(e);
+    }
+    fclose(f);
+    return true;
+}
 
 void usage() {
     fprintf(stderr,
             "usage: CS488 <scene.obj> [probe.hdr] [--accel kd|bvh] [--spp N] [--width W --height H] [--frames N]\n"
             "             [--out frame.png|frame.pfm] [--no-progressive] [--max-level N] [--eye x y z] [--lookat x y z]\n"
-            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--stats] [--headless]\n");
+            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--stats] [--headless]\n"
+            "             [--script events.txt] [--sequence PREFIX]\n");
 }
 
 bool parse(int argc, const char* argv[], Options& o) {
@@ -64,6 +136,8 @@ bool parse(int argc, const char* argv[], Options& o) {
         else if (a == "--seed") { if (!need(i, 1)) return false; o.seed = strtoull(argv[++i], nullptr, 0); o.have_seed = true; }
         else if (a == "--fov") { if (!need(i, 1)) return false; o.fov = (float)atof(argv[++i]); }
         else if (a == "--out") { if (!need(i, 1)) return false; o.out = argv[++i]; }
+        else if (a == "--script") { if (!need(i, 1)) return false; o.script = argv[++i]; }
+        else if (a == "--sequence") { if (!need(i, 1)) return false; o.sequence = argv[++i]; }
         else if (a == "--eye" || a == "--lookat" || a == "--up") {
             if (!need(i, 3)) return false;
             float* dst = a == "--eye" ? o.eye : (a == "--lookat" ? o.lookat : o.up);
@@ -71,6 +145,13 @@ bool parse(int argc, const char* argv[], Options& o) {
         } else { usage(); return false; }
     }
     return o.width > 0 && o.height > 0 && o.spp > 0 && o.frames >= 0;
+}
+
+int save_frame(PtContext* ctx, const std::string& path) {
+    const bool pfm = path.size() > 4 && path.compare(path.size() - 4, 4, ".pfm") == 0;
+    const int rc = pfm ? pt_save_pfm(ctx, 1, path.c_str()) : pt_save_png(ctx, 1, path.c_str());
+    if (rc == PT_OK) printf("Saved \"%s\".\n", path.c_str());  // src/cs488.h:231
+    return rc;
 }
 
 int die(PtContext* ctx, const char* what, int rc) {
@@ -128,35 +209,107 @@ int main(int argc, const char* argv[]) {
     rc = pt_build(ctx, opt.accel);
     if (rc != PT_OK) return die(ctx, "pt_build", rc);
     printf("Done.\n");
-    rc = pt_set_camera(ctx, opt.eye, opt.lookat, opt.up, opt.fov, 0.032f);
-    if (rc != PT_OK) return die(ctx, "pt_set_camera", rc);
     rc = pt_set_resolution(ctx, opt.width, opt.height);
     if (rc != PT_OK) return die(ctx, "pt_set_resolution", rc);
 
-    // the frame loop of src/cs488.h:2278-2324 without window events
+    std::vector<Event> events;
+    if (!opt.script.empty() && !read_script(opt.script, events)) {
+        fprintf(stderr, "cannot read the event script \"%s\"\n", opt.script.c_str());
+        pt_destroy(ctx);
+        return 2;
+    }
+
+    // the frame loop of src/cs488.h:2278-2324; scripted events stand in for glfwPollEvents
+    F3 eye = {opt.eye[0], opt.eye[1], opt.eye[2]}, lookat = {opt.lookat[0], opt.lookat[1], opt.lookat[2]};
+    const F3 up = normalize(F3{opt.up[0], opt.up[1], opt.up[2]});  // src/cs488.h:85
+    F3 view = normalize(lookat - eye), right = normalize(cross(view, up));
+    F3 prev_view = view, prev_right = right;
+    Pcg32 names;
+    bool recording = false, quit = false;
+    std::string recording_prefix;
+    int recorded = 0;
     double total_seconds = 0.0;
-    for (int frame = 0; frame < opt.frames; frame++) {
+    int frames_done = 0;
+    for (int frame = 0; frame < opt.frames && !quit; frame++) {
         auto t0 = std::chrono::high_resolution_clock::now();
-        if (!opt.progressive) {
+        for (const Event& e : events) {
+            if (e.frame != frame) continue;
+            if (e.kind == "key") {
+                const std::string& k = e.arg;
+                if (k == "W") { eye = eye + 0.1f * view; lookat = lookat + 0.1f * view; }        // SCLFACT, src/cs488.h:70
+                else if (k == "S") { eye = eye - 0.1f * view; lookat = lookat - 0.1f * view; }
+                else if (k == "Q") { eye = eye + 0.1f * up; lookat = lookat + 0.1f * up; }
+                else if (k == "Z") { eye = eye - 0.1f * up; lookat = lookat - 0.1f * up; }
+                else if (k == "A") { eye = eye - 0.1f * right; lookat = lookat - 0.1f * right; }
+                else if (k == "D") { eye = eye + 0.1f * right; lookat = lookat + 0.1f * right; }
+                else if (k == "ESCAPE") quit = true;
+                else if (k == "I") {
+                    char name[64];
+                    snprintf(name, sizeof(name), "output%d.png", int(1000.0 * names.rand()));
+                    if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(ctx, "saving the frame", rc);
+                } else if (k == "F") {
+                    if (!recording) {
+                        char name[64];
+                        snprintf(name, sizeof(name), "output%d", int(1000.0 * names.rand()));
+                        recording_prefix = name;
+                        printf("Saving \"%s_%%04d.png\"...\n", name);
+                        recording = true;
+                        recorded = 0;
+                        printf("(Recording started)\n");
+                    } else {
+                        recording = false;
+                        printf("(Recording done)\n");
+                    }
+                }
+            } else if (e.kind == "drag") {  // cursorPosFunc with the left button held, src/cs488.h:318-344
+                const float deg_to_rad = 3.14159265358979323846f / 180.0f;
+                const float xfact = -0.2f * e.dy, yfact = -0.2f * e.dx;  // ANGFACT, src/cs488.h:69
+                F3 v = view;
+                v = rotate_about(xfact * deg_to_rad, v, right);
+                v = rotate_about(yfact * deg_to_rad, v, up);
+                view = v;
+                lookat = eye + view;
+                right = cross(view, up);
+            } else if (e.kind == "save") {
+                if ((rc = save_frame(ctx, e.arg)) != PT_OK) return die(ctx, "saving the frame", rc);
+            }
+        }
+        if (quit) break;
+        view = normalize(lookat - eye);           // src/cs488.h:2284-2285
+        right = normalize(cross(view, up));
+        const float e3[3] = {eye.x, eye.y, eye.z}, l3[3] = {lookat.x, lookat.y, lookat.z}, u3[3] = {up.x, up.y, up.z};
+        rc = pt_set_camera(ctx, e3, l3, u3, opt.fov, 0.032f);
+        if (rc != PT_OK) return die(ctx, "pt_set_camera", rc);
+        if (differs(prev_view, view) || differs(prev_right, right) || !opt.progressive) {  // src/cs488.h:2287-2293
             rc = pt_reset(ctx);
             if (rc != PT_OK) return die(ctx, "pt_reset", rc);
+            prev_view = view;
+            prev_right = right;
         }
         rc = pt_render(ctx, opt.spp);
         if (rc == PT_OK) rc = pt_synchronize(ctx);
         if (rc != PT_OK) return die(ctx, "pt_render", rc);
         std::cout << pt_total_samples(ctx) << std::endl;  // src/cs488.h:1896
+        if (recording || !opt.sequence.empty()) {
+            char name[1200];
+            if (recording) {
+                snprintf(name, sizeof(name), "%s_%04d.png", recording_prefix.c_str(), recorded++);
+                if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(ctx, "saving a recorded frame", rc);
+            }
+            if (!opt.sequence.empty()) {
+                snprintf(name, sizeof(name), "%s%04d.png", opt.sequence.c_str(), frame);
+                if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(ctx, "saving a sequence frame", rc);
+            }
+        }
+        names.rand();  // src/cs488.h:2317
+        frames_done++;
         auto t1 = std::chrono::high_resolution_clock::now();
         const double seconds = std::chrono::duration_cast<std::chrono::duration<double>>(t1 - t0).count();
         total_seconds += seconds;
         std::cout << seconds << std::endl;  // src/cs488.h:2322
     }
 
-    if (!opt.out.empty()) {
-        const bool pfm = opt.out.size() > 4 && opt.out.compare(opt.out.size() - 4, 4, ".pfm") == 0;
-        rc = pfm ? pt_save_pfm(ctx, 1, opt.out.c_str()) : pt_save_png(ctx, 1, opt.out.c_str());
-        if (rc != PT_OK) return die(ctx, "saving the frame", rc);
-        printf("Saved \"%s\".\n", opt.out.c_str());  // src/cs488.h:231
-    }
+    if (!opt.out.empty() && (rc = save_frame(ctx, opt.out)) != PT_OK) return die(ctx, "saving the frame", rc);
     if (opt.stats) {
         uint64_t cnt[PT_CNT_COUNT];
         if (pt_get_counters(ctx, cnt) == PT_OK && total_seconds > 0) {
@@ -165,7 +318,7 @@ int main(int argc, const char* argv[]) {
                     rays, (double)cnt[PT_CNT_SAMPLES], rays / (double)cnt[PT_CNT_SAMPLES], cnt[PT_CNT_BOX_TESTS] / rays,
                     cnt[PT_CNT_TRI_TESTS] / rays, (unsigned long long)cnt[PT_CNT_NAN_SAMPLES]);
             fprintf(stderr, "%.2f Mrays/s  %.2f spp/s over %d frames (%.3f s)\n", rays / total_seconds * 1e-6,
-                    (double)opt.spp * opt.frames / total_seconds, opt.frames, total_seconds);
+                    (double)opt.spp * frames_done / total_seconds, frames_done, total_seconds);
         }
     }
     pt_destroy(ctx);

@@ -213,3 +213,31 @@ def test_fused_tail_gives_the_per_level_image(gpu_device, obj, accel):
             assert np.allclose(img, ref, rtol=1e-5, atol=1e-6)
         else:
             assert np.array_equal(img, ref)
+
+
+@pytest.mark.gpu
+def test_cli_scripted_input(gpu_device, tmp_path):
+    """Scripted events stand in for the window's callbacks (src/cs488.h:240-349): a translation keeps
+    accumulating (the reference restarts only when view direction or right vector change, :2266-2293),
+    a drag restarts, I / F write files named with the reference's generator, ESCAPE ends the loop."""
+    script = tmp_path / "events.txt"
+    script.write_text("# frame event\n1 key W\n2 key I\n3 drag 40 -10\n4 key F\n6 key F\n6 save %s\n8 key ESCAPE\n" % (tmp_path / "shot.pfm"))
+    r = subprocess.run([os.path.join(ROOT, "path_tracer_amd", "CS488"), scene_path("cornellbox.obj"), "--accel", "bvh", "--frames", "12",
+                        "--spp", "2", "--width", "48", "--height", "36", "--script", str(script), "--sequence", str(tmp_path / "seq_")],
+                       capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    i0 = lines.index("Done.") + 1
+    body = [ln for ln in lines[i0:] if not ln.startswith(("Saved", "Saving", "(Recording"))]
+    totals = body[0::2]
+    # frames 0..7 render (ESCAPE at 8); W at frame 1 keeps the count running, the drag at frame 3 restarts it
+    assert totals == ["2", "4", "6", "2", "4", "6", "8", "10"]
+    assert "(Recording started)" in r.stdout and "(Recording done)" in r.stdout
+    names = sorted(os.listdir(tmp_path))
+    stills = [n for n in names if re.fullmatch(r"output\d+\.png", n)]
+    recorded = [n for n in names if re.fullmatch(r"output\d+_\d{4}\.png", n)]
+    assert len(stills) == 1 and len(recorded) == 2          # frames 4 and 5 were recorded
+    assert len([n for n in names if n.startswith("seq_")]) == 8 and "shot.pfm" in names
+    # the generator is the reference's PCG32 (src/cs488.h:130-143): the I key at frame 2 comes after two per-frame draws
+    _, vals, _ = orc.pcg32(3)
+    assert stills[0] == "output%d.png" % int(1000.0 * float(vals[2]))

@@ -15,15 +15,24 @@ res = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 accel = pta.KD if (len(sys.argv) > 4 and sys.argv[4] == "kd") else pta.BVH
 s = pta.Scene(0)
-assert s.load(scene_path(obj))
-if obj.startswith("teapot"):
+spp = 10
+if obj == "sponza":  # the 3840x2160, 4 spp/frame courtyard workload of bench.py
+    import bench
+    from make_sponza import CAMERA
+    assert s.load(bench.sponza_path())
     s.load_env(scene_path("probe_64.hdr"))
+    s.set_camera(**CAMERA)
+    spp = 4
+else:
+    assert s.load(scene_path(obj))
+    if obj.startswith("teapot"):
+        s.load_env(scene_path("probe_64.hdr"))
 s.pre_calc(accel)
 if len(sys.argv) > 5:
     s.set_option(pta.OPT_TRAVERSAL, int(sys.argv[5], 0))
-s.set_resolution(res, res)
+s.set_resolution(*((3840, 2160) if obj == "sponza" else (res, res)))
 for _ in range(frames):
-    s.pathtrace(10)
+    s.pathtrace(spp)
 s.synchronize()
 c = s.counters()
 print("rays", c[0], "samples", c[3])
