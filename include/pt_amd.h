@@ -67,10 +67,13 @@ enum {
                                  the per-ray reciprocal plus one exact correction step instead of the division
                                  sequence (default on); bits 4..7: k of the node phase's early leave rule (default 4,
                                  0 = none); bit 2: refill a wave only when all its lanes are idle (measurement) */
-    PT_OPT_TAIL_LEVEL = 9     /* bounce levels from this one on are finished by one fused launch in which every
+    PT_OPT_TAIL_LEVEL = 9,    /* bounce levels from this one on are finished by one fused launch in which every
                                  workgroup alternates trace and shade on its own queue region (default 6, the level
                                  after Russian roulette starts, src/cs488.h:2153; 0 = one launch per level and stage).
                                  Same device code either way, so the image does not depend on it */
+    PT_OPT_BUILD_THREADS = 10 /* host threads pt_build may use for the tree (0 = all, default; 1 = none extra).  Large
+                                 subtrees near the root are built concurrently and spliced in at their sequential
+                                 positions: the tree is the same for every value */
 };
 
 /* Counter indices for pt_get_counters (all cumulative since pt_reset_counters). */

@@ -6,9 +6,16 @@
 // The kd builder evaluates the same candidate planes with the same cost arithmetic in the same
 // order, but counts the triangles on each side by binary search in per-axis sorted lists
 // (O(n log n) a node) where the reference recounts every triangle for every candidate (O(n^2)).
+//
+// Both builders are recursive and the two subtrees of a node do not depend on each other, so near
+// the root (large subtrees, first few levels) the left subtree is built by another thread into a
+// tree of its own and spliced in afterwards at the position the sequential recursion would have
+// given it: node and reference numbering are exactly those of the single-threaded build.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <future>
+#include <thread>
 
 #include "scene.h"
 
@@ -37,13 +44,34 @@ struct Bounds {
     }
 };
 
-struct BvhBuilder {
-    const HostMesh& mesh;
-    HostTree& tree;
-    std::vector<float> centroid[3];
-    int deepest = 0;
+// Subtrees of at least this many triangles, at most this deep, get a thread of their own.
+enum { PARALLEL_MIN_TRIS = 4096, PARALLEL_MAX_DEPTH = 4 };
 
-    BvhBuilder(const HostMesh& m, HostTree& t) : mesh(m), tree(t) {
+bool worth_a_thread(int n, int depth, int threads) {
+    if (threads == 0) threads = (int)std::thread::hardware_concurrency();
+    return threads > 1 && n >= PARALLEL_MIN_TRIS && depth < PARALLEL_MAX_DEPTH;
+}
+
+// Appends subtree `sub` (node 0 = its root, children by index, leaves by first/count into its own
+// refs) to `tree`, as the nodes [at, at + sub.nodes.size()).
+void splice(HostTree& tree, const HostTree& sub, int at, int skip_root, int root_id) {
+    // node k of `sub` becomes at + k - skip_root, except its root when that already exists as root_id
+    const int ref_base = (int)tree.refs.size();
+    auto renumber = [&](int k) { return (skip_root && k == 0) ? root_id : at + k - skip_root; };
+    for (size_t k = 0; k < sub.nodes.size(); k++) {
+        HostTree::Node nd = sub.nodes[k];
+        if (nd.left >= 0) { nd.left = renumber(nd.left); nd.right = renumber(nd.right); }
+        else nd.first += ref_base;
+        if (skip_root && k == 0) tree.nodes[root_id] = nd; else tree.nodes.push_back(nd);
+    }
+    tree.refs.insert(tree.refs.end(), sub.refs.begin(), sub.refs.end());
+}
+
+struct BvhShared {
+    const HostMesh& mesh;
+    std::vector<float> centroid[3];
+    int threads;
+    BvhShared(const HostMesh& m, int threads_) : mesh(m), threads(threads_) {
         const int n = mesh.num_tris();
         for (int a = 0; a < 3; a++) centroid[a].resize(n);
         for (int i = 0; i < n; i++) {
@@ -51,6 +79,16 @@ struct BvhBuilder {
             centroid[0][i] = c.x; centroid[1][i] = c.y; centroid[2][i] = c.z;
         }
     }
+};
+
+struct BvhBuilder {
+    const HostMesh& mesh;
+    const std::vector<float>* centroid;
+    HostTree& tree;
+    const BvhShared& shared;
+    int deepest = 0;
+
+    BvhBuilder(const BvhShared& s, HostTree& t) : mesh(s.mesh), centroid(s.centroid), tree(t), shared(s) {}
 
     void grow_tri(Bounds& b, int t) const { b.grow(mesh.p(t, 0)); b.grow(mesh.p(t, 1)); b.grow(mesh.p(t, 2)); }
 
@@ -112,6 +150,23 @@ struct BvhBuilder {
         Bounds lb, rb;
         for (int t : lo_ids) grow_tri(lb, t);
         for (int t : hi_ids) grow_tri(rb, t);
+        if (worth_a_thread(n, depth, shared.threads)) {
+            // the right subtree in this thread, into a tree of its own as well: its place in the
+            // numbering is known only when the left one is complete
+            HostTree left_tree, right_tree;
+            BvhBuilder lb_builder(shared, left_tree), rb_builder(shared, right_tree);
+            auto left_done = std::async(std::launch::async, [&]() { lb_builder.emit(lo_ids, lb, depth + 1); });
+            rb_builder.emit(hi_ids, rb, depth + 1);
+            left_done.get();
+            const int l = (int)tree.nodes.size();
+            splice(tree, left_tree, l, 0, -1);
+            const int r = (int)tree.nodes.size();
+            splice(tree, right_tree, r, 0, -1);
+            tree.nodes[id].left = l;
+            tree.nodes[id].right = r;
+            deepest = std::max(deepest, std::max(lb_builder.deepest, rb_builder.deepest));
+            return id;
+        }
         const int l = emit(lo_ids, lb, depth + 1);
         tree.nodes[id].left = l;
         const int r = emit(hi_ids, rb, depth + 1);
@@ -120,13 +175,10 @@ struct BvhBuilder {
     }
 };
 
-struct KdBuilder {
-    const HostMesh& mesh;
-    HostTree& tree;
+struct KdShared {
     std::vector<float> tmin[3], tmax[3];
-    int deepest = 0;
-
-    KdBuilder(const HostMesh& m, HostTree& t) : mesh(m), tree(t) {
+    int threads;
+    KdShared(const HostMesh& mesh, int threads_) : threads(threads_) {
         const int n = mesh.num_tris();
         for (int a = 0; a < 3; a++) {
             tmin[a].resize(n); tmax[a].resize(n);
@@ -137,6 +189,16 @@ struct KdBuilder {
             }
         }
     }
+};
+
+struct KdBuilder {
+    const KdShared& shared;
+    const std::vector<float>* tmin;
+    const std::vector<float>* tmax;
+    HostTree& tree;
+    int deepest = 0;
+
+    KdBuilder(const KdShared& s, HostTree& t) : shared(s), tmin(s.tmin), tmax(s.tmax), tree(t) {}
 
     static Bounds from_box(const float* b) {
         Bounds r;
@@ -211,6 +273,21 @@ struct KdBuilder {
             if (tmax[axis_best][t] > value_best) rids.push_back(t);
         }
         std::vector<int>().swap(ids);  // the parent's list is not needed below this point
+        if (worth_a_thread(n, depth, shared.threads)) {
+            // each child grows in a tree of its own whose node 0 is a copy of the child; the
+            // descendants are appended in the sequential order: all of the left child's, then the right's
+            HostTree left_tree, right_tree;
+            left_tree.nodes.push_back(tree.nodes[l]);
+            right_tree.nodes.push_back(tree.nodes[l + 1]);
+            KdBuilder lbuild(shared, left_tree), rbuild(shared, right_tree);
+            auto left_done = std::async(std::launch::async, [&]() { lbuild.grow(0, lids, depth + 1); });
+            rbuild.grow(0, rids, depth + 1);
+            left_done.get();
+            splice(tree, left_tree, (int)tree.nodes.size(), 1, l);
+            splice(tree, right_tree, (int)tree.nodes.size(), 1, l + 1);
+            deepest = std::max(deepest, std::max(lbuild.deepest, rbuild.deepest));
+            return;
+        }
         grow(l, lids, depth + 1);
         grow(l + 1, rids, depth + 1);
     }
@@ -218,12 +295,13 @@ struct KdBuilder {
 
 }  // namespace
 
-void build_bvh(const HostMesh& mesh, HostTree& tree) {
+void build_bvh(const HostMesh& mesh, HostTree& tree, int threads) {
     tree = HostTree();
     tree.kind = 0;
     const int n = mesh.num_tris();
     if (n == 0) return;
-    BvhBuilder b(mesh, tree);
+    BvhShared shared(mesh, threads);
+    BvhBuilder b(shared, tree);
     std::vector<int> ids(n);
     Bounds box;
     for (int i = 0; i < n; i++) { ids[i] = i; b.grow_tri(box, i); }
@@ -232,12 +310,13 @@ void build_bvh(const HostMesh& mesh, HostTree& tree) {
     tree.max_depth = b.deepest;
 }
 
-void build_kd(const HostMesh& mesh, HostTree& tree) {
+void build_kd(const HostMesh& mesh, HostTree& tree, int threads) {
     tree = HostTree();
     tree.kind = 1;
     const int n = mesh.num_tris();
     if (n == 0) return;
-    KdBuilder b(mesh, tree);
+    KdShared shared(mesh, threads);
+    KdBuilder b(shared, tree);
     std::vector<int> ids(n);
     Bounds box;
     for (int i = 0; i < n; i++) {

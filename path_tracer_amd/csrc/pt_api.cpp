@@ -87,6 +87,7 @@ struct PtContext {
     size_t max_batch = (size_t)1 << 24;
     int queue_factor = 4;
     int lds_nodes_opt = 256;
+    int build_threads = 0;  // host threads of the tree builders, 0 = all
     int tail_level = 6;  // levels from here on run in the fused kernel; Russian roulette starts at level 5 (src/cs488.h:2153)
 
     // device scene
@@ -630,6 +631,9 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             c->scene.lds_nodes = c->lds_nodes_opt < c->scene.n_nodes ? c->lds_nodes_opt : c->scene.n_nodes;
             break;
         case PT_OPT_TRAVERSAL: c->traversal = (int)value; break;
+        case PT_OPT_BUILD_THREADS:
+            if (value > 256) return fail(c, PT_ERR_INVALID_ARG, "more than 256 builder threads");
+            c->build_threads = (int)value; break;
         case PT_OPT_TAIL_LEVEL:
             if (value > 64) return fail(c, PT_ERR_INVALID_ARG, "tail level above 64");
             c->tail_level = (int)value; break;
@@ -650,6 +654,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
         case PT_OPT_LDS_NODES: *value = (uint64_t)c->lds_nodes_opt; break;
         case PT_OPT_TRAVERSAL: *value = (uint64_t)c->traversal; break;
         case PT_OPT_TAIL_LEVEL: *value = (uint64_t)c->tail_level; break;
+        case PT_OPT_BUILD_THREADS: *value = (uint64_t)c->build_threads; break;
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
     return PT_OK;
@@ -771,7 +776,7 @@ int pt_build(PtContext* c, int accel) {
         if (rc != PT_OK) return rc;
     }
     c->accel = accel;
-    if (accel == PT_ACCEL_KD) build_kd(c->mesh, c->tree); else build_bvh(c->mesh, c->tree);
+    if (accel == PT_ACCEL_KD) build_kd(c->mesh, c->tree, c->build_threads); else build_bvh(c->mesh, c->tree, c->build_threads);
     if (c->device == PT_DEVICE_NONE) return PT_OK;  // tree available through pt_get_tree; not renderable
     PT_HIP(c, hipSetDevice(c->device));
     int rc = flatten_and_upload(c);

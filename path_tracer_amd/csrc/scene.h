@@ -78,7 +78,8 @@ bool save_pfm(const char* path, const float* rgb_bottom_up, int w, int h, std::s
 void quantise_image(const float* rgb_bottom_up, int w, int h, std::vector<uint8_t>& out);
 
 // ---- accel_build.cpp ----
-void build_bvh(const HostMesh& mesh, HostTree& tree);  // src/cs488.h:1490-1667
-void build_kd(const HostMesh& mesh, HostTree& tree);   // src/cs488.h:1229-1320, 1388-1400
+// threads: 0 = as many as the host offers, 1 = single-threaded; the tree does not depend on it
+void build_bvh(const HostMesh& mesh, HostTree& tree, int threads = 0);  // src/cs488.h:1490-1667
+void build_kd(const HostMesh& mesh, HostTree& tree, int threads = 0);   // src/cs488.h:1229-1320, 1388-1400
 
 }  // namespace pt

@@ -179,3 +179,29 @@ def test_host_only_context_refuses_gpu_work():
         with pytest.raises(pta.PtError) as e:
             call()
         assert e.value.code == pta.ERR_NOT_READY
+
+
+def test_parallel_builders_give_the_sequential_trees():
+    """Large subtrees near the root are built by other threads and spliced in; node numbering, boxes and
+    leaf references must be those of the single-threaded recursion (a procedural mesh large enough for
+    several levels of concurrent subtrees)."""
+    import path_tracer_amd as pta
+    rng = np.random.default_rng(11)
+    n = 60000
+    centre = rng.random((n, 1, 3)).astype(np.float32) * 4 - 2
+    pos = (centre + (rng.random((n, 3, 3)).astype(np.float32) - 0.5) * 0.05).reshape(n, 9)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (n, 3)).reshape(n, 9)
+    trees = {}
+    for accel in (pta.BVH, pta.KD):
+        for threads in (1, 0, 8):
+            s = pta.Scene(pta.DEVICE_NONE)
+            s.set_mesh(pos, nrm)
+            s.set_option(pta.OPT_BUILD_THREADS, threads)
+            s.pre_calc(accel)
+            trees[(accel, threads)] = s.get_tree()
+        ref = trees[(accel, 1)]
+        for threads in (0, 8):
+            got = trees[(accel, threads)]
+            assert got["max_depth"] == ref["max_depth"]
+            for key in ("left", "right", "first", "count", "box", "refs"):
+                assert np.array_equal(got[key], ref[key]), (accel, threads, key)
