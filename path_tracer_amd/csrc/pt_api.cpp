@@ -243,7 +243,9 @@ int flatten_and_upload(PtContext* c) {
     };
     // kd-tree leaves repeat triangles; their records are stored per leaf only while that stays small
     // enough to live in the caches (64 bytes a reference), otherwise once per triangle behind `refs`
-    const bool kd = t.kind == 1 && t.refs.size() > 32768;
+    // -- and also for a mesh small enough that the whole tree is staged in LDS, where a leaf
+    // reference then costs 4 bytes instead of 64
+    const bool kd = t.kind == 1 && (t.refs.size() > 32768 || hm.num_tris() <= 256);
     std::vector<int> refs;
     std::vector<float4> isect;
     if (kd) {
@@ -342,6 +344,7 @@ int flatten_and_upload(PtContext* c) {
     s.n_tris = nt;
     s.leaf_inline = kd ? 0 : 1;
     s.n_records = (int)(isect.size() / 4);
+    s.n_refs = (int)refs.size();
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)
         for (int k = 0; k < 6; k++)

@@ -24,8 +24,8 @@ __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int 
                                                    int leave_k) {
     extern __shared__ float4 lds_nodes[];
     __shared__ __attribute__((aligned(16))) unsigned int s_stat[4];
-    __shared__ __attribute__((aligned(16))) int s_stack[LDS_STACK * 256];
-    __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LDS_STACK * 256 : 4];
+    __shared__ __attribute__((aligned(16))) int s_stack[LdsStack<KD>::ENTRIES * 256];
+    __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LdsStack<KD>::ENTRIES * 256 : 4];
     __shared__ int s_out;
     const int blk = blockIdx.x;
     const int nb = b.blocks;
@@ -51,10 +51,10 @@ template <bool KD, int SLAB>
 void launch_tail_variant(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level0, int levels, int max_level,
                          QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount, unsigned long long* block_stats,
                          int leave_k) {
-    const size_t lds = (size_t)scene.lds_nodes * 64;
-    if (scene.lds_nodes >= scene.n_nodes && scene.leaf_inline && scene.n_records <= LDS_RECORDS_MAX)
-        hipLaunchKernelGGL((tail_kernel<KD, SLAB, true>), dim3(batch.blocks), dim3(256), lds + (size_t)scene.n_records * 64, cfg.stream,
-                           scene, batch, level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k);
+    const size_t lds = dynamic_lds_bytes(scene);
+    if (fits_lds(scene))
+        hipLaunchKernelGGL((tail_kernel<KD, SLAB, true>), dim3(batch.blocks), dim3(256), lds, cfg.stream, scene, batch, level0,
+                           levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k);
     else
         hipLaunchKernelGGL((tail_kernel<KD, SLAB, false>), dim3(batch.blocks), dim3(256), lds, cfg.stream, scene, batch, level0,
                            levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k);

@@ -174,7 +174,8 @@ __device__ __forceinline__ void node_step(const float4& q0, const float4& q1, co
 
 // The first LDS_STACK entries of a lane's traversal stack live in LDS (entry e of lane t at
 // [e * 256 + t]: consecutive lanes on consecutive banks), deeper ones in the lane's scratch array.
-enum { LDS_STACK = 12 };
+enum { LDS_STACK_BVH = 12, LDS_STACK_KD = 8 };  // a kd-tree entry is two words (node, entry distance)
+template <bool KD> struct LdsStack { enum { ENTRIES = KD ? LDS_STACK_KD : LDS_STACK_BVH }; };
 // Triangles a lane tests per visit of the leaf phase.
 enum { LEAF_BURST = 4 };
 
@@ -183,14 +184,24 @@ enum : int { NO_RAY = INT_MIN };
 
 // ALL_LDS: every interior node and every (leaf-ordered) intersection record is staged in LDS --
 // small scenes -- so neither the walk nor the leaf phase has a global-memory path.
-enum { LDS_RECORDS_MAX = 256 };
+enum { LDS_RECORDS_MAX = 256, LDS_REFS_MAX = 2048 };
+
+// May the ALL_LDS instantiation serve this scene?  (host side; decides the dynamic LDS size too)
+inline bool fits_lds(const SceneGpu& sc) {
+    return sc.lds_nodes >= sc.n_nodes && sc.n_records <= LDS_RECORDS_MAX && (sc.leaf_inline || sc.n_refs <= LDS_REFS_MAX);
+}
+inline size_t dynamic_lds_bytes(const SceneGpu& sc) {
+    size_t b = (size_t)sc.lds_nodes * 64;
+    if (fits_lds(sc)) b += (size_t)sc.n_records * 64 + (sc.leaf_inline ? 0 : (size_t)sc.n_refs * 4);
+    return b;
+}
 // LDS a workgroup needs for the walk: the staged nodes (and records), four counters, the stacks.
 template <bool KD>
 struct TraceLds {
     float4* nodes;          // dynamic LDS: lds_nodes node records, then (ALL_LDS) the leaf records
     unsigned int* stat;     // 4: hits, slab tests, triangle tests, next ray of the region
-    int* stack;             // LDS_STACK * 256
-    float* stack_t;         // LDS_STACK * 256 (kd-tree only)
+    int* stack;             // LdsStack<KD>::ENTRIES * 256
+    float* stack_t;         // the same number of entry distances (kd-tree only)
 };
 
 // Copies the top of the tree (and, with ALL_LDS, the leaf records) into LDS; every thread of the
@@ -200,8 +211,13 @@ __device__ __forceinline__ void stage_tree(const SceneGpu& sc, float4* lds_nodes
     const int staged = sc.lds_nodes;
     for (int k = threadIdx.x; k < staged * 4; k += blockDim.x) lds_nodes[k] = sc.nodes[k];
     float4* lds_records = lds_nodes + 4 * staged;
-    if (ALL_LDS)
+    if (ALL_LDS) {
         for (int k = threadIdx.x; k < sc.n_records * 4; k += blockDim.x) lds_records[k] = sc.isect[k];
+        if (!sc.leaf_inline) {  // leaves as index lists behind the records
+            int* lds_refs = reinterpret_cast<int*>(lds_records + 4 * sc.n_records);
+            for (int k = threadIdx.x; k < sc.n_refs; k += blockDim.x) lds_refs[k] = sc.refs[k];
+        }
+    }
 }
 
 // Closest hits for the n rays at [region, region + n) of the queue; called by all 256 threads of
@@ -211,6 +227,7 @@ template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS>
 __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* __restrict__ ray_o,
                                              const float4* __restrict__ ray_d, float4* __restrict__ hit, int n, size_t region,
                                              unsigned long long* __restrict__ block_stats, int leave_k, const TraceLds<KD>& lds) {
+    constexpr int LDS_STACK = LdsStack<KD>::ENTRIES;
     float4* const lds_nodes = lds.nodes;
     unsigned int* const s_stat = lds.stat;
     int* const s_stack = lds.stack;
@@ -218,6 +235,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     const int blk = blockIdx.x;
     const int staged = sc.lds_nodes;
     float4* const lds_records = lds_nodes + 4 * staged;
+    const int* const lds_refs = reinterpret_cast<const int*>(lds_records + 4 * sc.n_records);
     if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
@@ -341,11 +359,12 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         if ((unsigned int)cur > (unsigned int)NO_RAY) {
             const int off = ~cur;
             if (KD && !sc.leaf_inline) {
-                if (leaf_k == 0) leaf_n = sc.refs[off];
+                if (leaf_k == 0) leaf_n = ALL_LDS ? lds_refs[off] : sc.refs[off];
                 const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
                 for (; leaf_k < stop; leaf_k++) {
                     if (COUNT) n_tri++;
-                    const float4* rec = sc.isect + 4 * (size_t)sc.refs[off + 1 + leaf_k];
+                    const float4* rec = ALL_LDS ? lds_records + 4 * lds_refs[off + 1 + leaf_k]
+                                                : sc.isect + 4 * (size_t)sc.refs[off + 1 + leaf_k];
                     triangle_test<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, best);
                 }
             } else {

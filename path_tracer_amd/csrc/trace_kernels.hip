@@ -17,8 +17,8 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                                                     unsigned long long* __restrict__ block_stats, int leave_k) {
     extern __shared__ float4 lds_nodes[];
     __shared__ __attribute__((aligned(16))) unsigned int s_stat[4];
-    __shared__ __attribute__((aligned(16))) int s_stack[LDS_STACK * 256];
-    __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LDS_STACK * 256 : 4];
+    __shared__ __attribute__((aligned(16))) int s_stack[LdsStack<KD>::ENTRIES * 256];
+    __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LdsStack<KD>::ENTRIES * 256 : 4];
     const int blk = blockIdx.x;
     int n;
     if (n_ptr) {
@@ -58,10 +58,9 @@ __global__ void unpack_hits_kernel(const float4* __restrict__ hit, int n, int* t
 template <bool KD, bool COUNT, int SLAB, bool DYNAMIC>
 void launch_variant(const LaunchCfg& cfg, const SceneGpu& scene, const float4* ray_o, const float4* ray_d, float4* hit,
                     const int* n_rays, int n_fixed, int grid_blocks, int cap_block, unsigned long long* block_stats, int leave_k) {
-    const size_t lds = (size_t)scene.lds_nodes * 64;
-    if (scene.lds_nodes >= scene.n_nodes && scene.leaf_inline && scene.n_records <= LDS_RECORDS_MAX)
-        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, true>), dim3(grid_blocks), dim3(256),
-                           lds + (size_t)scene.n_records * 64, cfg.stream, scene,
+    const size_t lds = dynamic_lds_bytes(scene);
+    if (fits_lds(scene))
+        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, true>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
                            ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
     else
         hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, false>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
