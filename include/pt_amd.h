@@ -71,9 +71,12 @@ enum {
                                  workgroup alternates trace and shade on its own queue region (default 6, the level
                                  after Russian roulette starts, src/cs488.h:2153; 0 = one launch per level and stage).
                                  Same device code either way, so the image does not depend on it */
-    PT_OPT_BUILD_THREADS = 10 /* host threads pt_build may use for the tree (0 = all, default; 1 = none extra).  Large
+    PT_OPT_BUILD_THREADS = 10,/* host threads pt_build may use for the tree (0 = all, default; 1 = none extra).  Large
                                  subtrees near the root are built concurrently and spliced in at their sequential
                                  positions: the tree is the same for every value */
+    PT_OPT_OBJ_EXTENDED = 11  /* 1: pt_load_obj also accepts what the reference's reader does not (src/cs488.h:1059 reads
+                                 three vertices per face, :944-946 positive indices only): polygons as triangle fans,
+                                 negative indices, face lines of any length.  Default 0 = the reference's behaviour */
 };
 
 /* Counter indices for pt_get_counters (all cumulative since pt_reset_counters). */

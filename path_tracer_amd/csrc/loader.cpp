@@ -115,7 +115,7 @@ void read_mtl(const std::string& path, const std::string& dir, std::vector<HostM
 
 }  // namespace
 
-bool load_obj(const char* path, HostMesh& mesh, std::string& err) {
+bool load_obj(const char* path, HostMesh& mesh, std::string& err, bool extended) {
     mesh.clear();
     FILE* fp = fopen(path, "r");
     if (!fp) {
@@ -144,7 +144,40 @@ bool load_obj(const char* path, HostMesh& mesh, std::string& err) {
     bool have_normals = true, have_uvs = true, any_material = false;
     int current = 0;
     float f[3];
+    std::string long_line;  // extended mode: a face line of any length
     while (fgets(line, 80, fp)) {
+        if (extended && line[0] == 'f') {
+            // Beyond the reference: polygons become triangle fans (v0, vi, vi+1) and negative
+            // indices count back from the end of the tables read so far.
+            long_line = line;
+            while (!long_line.empty() && long_line.back() != '\n' && fgets(line, 80, fp)) long_line += line;
+            std::vector<FaceRef> corner;
+            const int nv_now = (int)vs.size() / 3, nn_now = (int)vns.size() / 3, nt_now = (int)vts.size() / 2;
+            size_t pos = 1;
+            while (pos < long_line.size()) {
+                while (pos < long_line.size() && isspace((unsigned char)long_line[pos])) pos++;
+                size_t end = pos;
+                while (end < long_line.size() && !isspace((unsigned char)long_line[end])) end++;
+                if (end > pos) {
+                    FaceRef r = parse_ref(long_line.substr(pos, end - pos).c_str());
+                    if (r.v < 0) r.v += nv_now + 1;
+                    if (r.t < 0) r.t += nt_now + 1;
+                    if (r.n < 0) r.n += nn_now + 1;
+                    corner.push_back(r);
+                }
+                pos = end;
+            }
+            for (size_t k = 1; k + 1 < corner.size(); k++) {
+                face_mat.push_back(current);
+                const FaceRef tri[3] = {corner[0], corner[k], corner[k + 1]};
+                for (const FaceRef& r : tri) {
+                    if (r.n == 0) have_normals = false;
+                    if (r.t == 0) have_uvs = false;
+                    refs.push_back(r);
+                }
+            }
+            continue;
+        }
         if (line[0] == 'v') {
             if (line[1] == 'n') {
                 scan_floats(line + 2, f, 3);

@@ -15,7 +15,9 @@
 //   --eye/--lookat/--up x y z, --fov deg   camera globals         (src/cs488.h:75,83-85)
 // Headless additions: --frames N (default 10), --out file.png|.pfm (the `I` key's
 // FrameBuffer.save, src/cs488.h:249-253), --seed N, --device N, --stats (ray statistics and
-// Mrays/s on stderr after the last frame), --sequence PREFIX (every frame to PREFIX%04d.png).
+// Mrays/s on stderr after the last frame), --sequence PREFIX (every frame to PREFIX%04d.png),
+// --obj-polygons (faces with more than three vertices as triangle fans, negative indices; the
+// reference reads three vertices per face, src/cs488.h:1059).
 //
 // Window input is replaced by a script (--script FILE), one event per line, applied where the
 // reference polls events, i.e. before the frame with that index is rendered (src/cs488.h:2283):
@@ -50,6 +52,7 @@ struct Options {
     float eye[3] = {0.0f, 0.0f, 1.5f}, lookat[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
     float fov = 45.0f;
     std::string out, script, sequence;
+    bool obj_extended = false;
 };
 
 struct Event {
@@ -115,7 +118,7 @@ void usage() {
             "usage: CS488 <scene.obj> [probe.hdr] [--accel kd|bvh] [--spp N] [--width W --height H] [--frames N]\n"
             "             [--out frame.png|frame.pfm] [--no-progressive] [--max-level N] [--eye x y z] [--lookat x y z]\n"
             "             [--up x y z] [--fov deg] [--seed N] [--device N] [--stats] [--headless]\n"
-            "             [--script events.txt] [--sequence PREFIX]\n");
+            "             [--script events.txt] [--sequence PREFIX] [--obj-polygons]\n");
 }
 
 bool parse(int argc, const char* argv[], Options& o) {
@@ -136,6 +139,7 @@ bool parse(int argc, const char* argv[], Options& o) {
         else if (a == "--seed") { if (!need(i, 1)) return false; o.seed = strtoull(argv[++i], nullptr, 0); o.have_seed = true; }
         else if (a == "--fov") { if (!need(i, 1)) return false; o.fov = (float)atof(argv[++i]); }
         else if (a == "--out") { if (!need(i, 1)) return false; o.out = argv[++i]; }
+        else if (a == "--obj-polygons") o.obj_extended = true;
         else if (a == "--script") { if (!need(i, 1)) return false; o.script = argv[++i]; }
         else if (a == "--sequence") { if (!need(i, 1)) return false; o.sequence = argv[++i]; }
         else if (a == "--eye" || a == "--lookat" || a == "--up") {
@@ -176,6 +180,7 @@ int main(int argc, const char* argv[]) {
     // setupScene, src/main.cpp:6-27
     if (!opt.positional.empty()) {
         const char* obj = opt.positional[0].c_str();
+        if (opt.obj_extended) pt_set_option(ctx, PT_OPT_OBJ_EXTENDED, 1);
         printf("Loading \"%s\"...\n", obj);  // src/cs488.h:712
         rc = pt_load_obj(ctx, obj);
         if (rc == PT_OK) {

@@ -87,6 +87,7 @@ struct PtContext {
     size_t max_batch = (size_t)1 << 24;
     int queue_factor = 4;
     int lds_nodes_opt = 256;
+    int obj_extended = 0;   // pt_load_obj also takes polygons and negative indices
     int build_threads = 0;  // host threads of the tree builders, 0 = all
     int tail_level = 6;  // levels from here on run in the fused kernel; Russian roulette starts at level 5 (src/cs488.h:2153)
 
@@ -634,6 +635,7 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             c->scene.lds_nodes = c->lds_nodes_opt < c->scene.n_nodes ? c->lds_nodes_opt : c->scene.n_nodes;
             break;
         case PT_OPT_TRAVERSAL: c->traversal = (int)value; break;
+        case PT_OPT_OBJ_EXTENDED: c->obj_extended = value != 0; break;
         case PT_OPT_BUILD_THREADS:
             if (value > 256) return fail(c, PT_ERR_INVALID_ARG, "more than 256 builder threads");
             c->build_threads = (int)value; break;
@@ -658,6 +660,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
         case PT_OPT_TRAVERSAL: *value = (uint64_t)c->traversal; break;
         case PT_OPT_TAIL_LEVEL: *value = (uint64_t)c->tail_level; break;
         case PT_OPT_BUILD_THREADS: *value = (uint64_t)c->build_threads; break;
+        case PT_OPT_OBJ_EXTENDED: *value = (uint64_t)c->obj_extended; break;
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
     return PT_OK;
@@ -668,7 +671,7 @@ int pt_load_obj(PtContext* c, const char* path) {
     if (!c || !path) return PT_ERR_INVALID_ARG;
     c->built = false;
     std::string err;
-    if (!load_obj(path, c->mesh, err)) {
+    if (!load_obj(path, c->mesh, err, c->obj_extended != 0)) {
         FILE* probe = fopen(path, "r");
         if (!probe) return fail(c, PT_ERR_IO, err);
         fclose(probe);

@@ -63,7 +63,9 @@ struct HostTree {
 
 // ---- loader.cpp ----
 // TriangleMesh::load (src/cs488.h:703-788).  false: file missing or no triangle in it.
-bool load_obj(const char* path, HostMesh& mesh, std::string& err);
+// extended = false is the reference's reader; true additionally accepts polygons (fan triangulation), negative
+// indices and face lines longer than the reference's 79-byte reads
+bool load_obj(const char* path, HostMesh& mesh, std::string& err, bool extended = false);
 // TriangleMesh::createSingleTriangle (src/cs488.h:814-835)
 void make_single_triangle(HostMesh& mesh);
 

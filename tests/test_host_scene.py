@@ -205,3 +205,28 @@ def test_parallel_builders_give_the_sequential_trees():
             assert got["max_depth"] == ref["max_depth"]
             for key in ("left", "right", "first", "count", "box", "refs"):
                 assert np.array_equal(got[key], ref[key]), (accel, threads, key)
+
+
+def test_obj_extensions_are_opt_in(tmp_path):
+    """A quad with negative indices: the reference's reader takes the first three corners of a face and
+    positive indices only (src/cs488.h:1059, 944-946); PT_OPT_OBJ_EXTENDED fans polygons out and resolves
+    indices that count back from the end of the tables."""
+    import path_tracer_amd as pta
+    obj = tmp_path / "quad.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\n"
+                   "f 1 2 3 4 5\n"
+                   "f -5 -4 -3 -2\n")
+    s = pta.Scene(pta.DEVICE_NONE)
+    assert not s.load(str(obj))            # -5 is not a valid index for the reference's reader
+    s.set_option(pta.OPT_OBJ_EXTENDED, 1)
+    assert s.load(str(obj))
+    assert s.num_triangles() == 3 + 2
+    pos = s.get_mesh()[0].reshape(-1, 3, 3)
+    quad = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 2, 0]], np.float32)
+    assert np.array_equal(pos[0], quad[[0, 1, 2]]) and np.array_equal(pos[1], quad[[0, 2, 3]]) and np.array_equal(pos[2], quad[[0, 3, 4]])
+    assert np.array_equal(pos[3], quad[[0, 1, 2]]) and np.array_equal(pos[4], quad[[0, 2, 3]])
+    # the default reader still takes three corners of the pentagon
+    s2 = pta.Scene(pta.DEVICE_NONE)
+    obj2 = tmp_path / "penta.obj"
+    obj2.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\nf 1 2 3 4 5\n")
+    assert s2.load(str(obj2)) and s2.num_triangles() == 1
