@@ -90,3 +90,50 @@ def test_nan_and_degenerate_rays(gpu_device):
     got = s.intersect(rays)
     assert np.array_equal(ref["tri"], got["tri"])
     assert np.array_equal(ref["t"].view(np.uint32), got["t"].view(np.uint32))
+
+
+def bounce_rays(s, rays, hits, rng, spp=2):
+    """The next-level ray population of a batch: from every hit point (interpolated from the
+    barycentrics, offset along the flat normal) a few cosine-distributed directions, plus the
+    straight-through continuation an alpha fork would trace."""
+    pos = s.get_mesh()[0].reshape(-1, 3, 3)
+    ok = hits["tri"] >= 0
+    tri = hits["tri"][ok]
+    b, g = hits["bary"][ok, 0:1], hits["bary"][ok, 1:2]
+    p = (1 - b - g) * pos[tri, 0] + b * pos[tri, 1] + g * pos[tri, 2]
+    n = np.cross(pos[tri, 1] - pos[tri, 0], pos[tri, 2] - pos[tri, 0])
+    n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)
+    n[np.einsum("ij,ij->i", n, rays[ok, 3:]) > 0] *= -1
+    p = np.repeat(p, spp, axis=0); nn = np.repeat(n, spp, axis=0)
+    u1, u2 = rng.random(len(p)), rng.random(len(p))
+    r, th = np.sqrt(u1), 2 * np.pi * u2
+    up = np.where(np.abs(nn[:, 2:3]) < 0.999, np.array([[0, 0, 1.0]]), np.array([[1.0, 0, 0]]))
+    tg = np.cross(up, nn); tg /= np.linalg.norm(tg, axis=1, keepdims=True)
+    bt = np.cross(nn, tg)
+    d = tg * (r * np.cos(th))[:, None] + bt * (r * np.sin(th))[:, None] + nn * np.sqrt(1 - u1)[:, None]
+    bounce = np.concatenate([p + 1e-4 * nn, d], axis=1)
+    through = np.concatenate([(1 - b - g) * pos[tri, 0] + b * pos[tri, 1] + g * pos[tri, 2] - 1e-4 * n, rays[ok, 3:]], axis=1)
+    return np.concatenate([bounce, through]).astype(np.float32)
+
+
+@pytest.mark.parametrize("obj,accel", [("cornellbox.obj", orc.BVH), ("cornellbox.obj", orc.KD), ("cornellball-glass.obj", orc.BVH),
+                                        ("teapot.obj", orc.BVH), ("teapot.obj", orc.KD)])
+def test_bounce_populations_parity(gpu_device, obj, accel):
+    """Three generations of secondary rays as the renderer produces them (origins on surfaces, offset by
+    epsilon, incoherent directions): several hundred thousand rays per scene, every one bit-identical."""
+    o = load_oracle_scene(obj, accel, textures=False)
+    s = load_gpu_scene(obj, accel)
+    s.set_resolution(256, 192)
+    rng = np.random.default_rng(17)
+    rays = s.camera_rays()
+    total = 0
+    for _ in range(3):
+        hits = s.intersect(rays)
+        check_batch(o, s, rays)
+        total += len(rays)
+        rays = bounce_rays(s, rays, hits, rng)
+        if len(rays) > 150000:
+            rays = rays[rng.permutation(len(rays))[:150000]]
+        if len(rays) == 0:
+            break
+    assert total > 50000
