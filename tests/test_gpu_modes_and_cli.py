@@ -58,6 +58,17 @@ def test_reciprocal_division_is_exact_on_a_slice(gpu_device):
     assert bad.returncode == 1  # the uncorrected product is caught by the same checker
 
 
+def test_refined_hardware_reciprocal_is_correctly_rounded(gpu_device):
+    """exact_reciprocal (v_rcp_f32 + one Newton step) against the IEEE quotient 1/d for every binary32 d with
+    2^-60 <= |d| <= 2^60: the whole sweep takes seconds; the raw v_rcp_f32 must be caught by the same checker."""
+    exe = os.path.join(ROOT, "tools", "verify_fast_rcp")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and re.search(r"2030043136 values checked, 0 mismatches", out.stdout), out.stdout + out.stderr
+    raw = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=120)
+    assert re.search(r"raw v_rcp_f32: 2030043136 values checked, [1-9]\d* mismatches", raw.stdout), raw.stdout
+
+
 def test_courtyard_stand_in_scene(gpu_device, tmp_path):
     """Small version of the sponza stand-in: every material kind, texture, probe; loader and hits
     against the oracle, image against the oracle."""
