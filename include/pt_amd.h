@@ -66,7 +66,9 @@ enum {
     PT_OPT_TRAVERSAL = 8,     /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab quotients from
                                  the per-ray reciprocal plus one exact correction step instead of the division
                                  sequence (default on); bits 4..7: k of the node phase's early leave rule (default 4,
-                                 0 = none); bit 2: refill a wave only when all its lanes are idle (measurement) */
+                                 0 = none); bit 2: refill a wave only when all its lanes are idle (measurement);
+                                 bits 8..14: idle lanes a wave waits for before it fetches new rays (0, the default: 32 for a
+                                 scene held entirely in LDS, else 16) */
     PT_OPT_TAIL_LEVEL = 9,    /* bounce levels from this one on are finished by one fused launch in which every
                                  workgroup alternates trace and shade on its own queue region (default 6, the level
                                  after Russian roulette starts, src/cs488.h:2153; 0 = one launch per level and stage).

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt_amd.so")
+LIB_PATH = os.environ.get("PT_AMD_LIB") or os.path.join(_HERE, "libpt_amd.so")  # the variable is for A/B measurements of builds
 
 BVH, KD = 0, 1
 LAMBERTIAN, METAL, GLASS = 0, 1, 2

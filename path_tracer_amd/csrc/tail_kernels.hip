@@ -68,7 +68,10 @@ hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchG
                        int max_level, QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount,
                        unsigned long long* block_stats) {
     const bool recip = (mode & 1) != 0;
-    const int leave_k = (mode >> 4) & 15;
+    // the refill threshold rides above leave_k; unset, a scene walked entirely in LDS waits for half a wave
+    // (short walks: fuller refills pay), any other for a quarter (long walks: idle lanes cost more)
+    const int refill = (mode >> 8) & 127 ? (mode >> 8) & 127 : (fits_lds(scene) ? 32 : 16);
+    const int leave_k = ((mode >> 4) & 15) | (refill << 8);
 #define PT_ARGS cfg, scene, batch, level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k
     if (kd) {
         if (recip) launch_tail_variant<true, SLAB_RECIP>(PT_ARGS); else launch_tail_variant<true, SLAB_DIVIDE>(PT_ARGS);

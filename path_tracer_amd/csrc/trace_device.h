@@ -27,7 +27,7 @@
 // none of its lanes remain or when they are outnumbered k to 1 by the lanes waiting at a leaf, so
 // neither code path runs nearly empty because of one long walk or one large leaf.  Lanes whose ray
 // is finished take the next rays of the region through an LDS counter (one atomic per refill) as
-// soon as a quarter of the wave is idle.  The first `lds_nodes` tree nodes (the top levels; nodes are numbered breadth-first) are
+// soon as half of the wave is idle (tunable).  The first `lds_nodes` tree nodes (the top levels; nodes are numbered breadth-first) are
 // copied into LDS by every workgroup that has work; the first LDS_STACK entries of every lane's
 // traversal stack live in LDS as well.
 #pragma once
@@ -226,7 +226,7 @@ __device__ __forceinline__ void stage_tree(const SceneGpu& sc, float4* lds_nodes
 template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS>
 __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* __restrict__ ray_o,
                                              const float4* __restrict__ ray_d, float4* __restrict__ hit, int n, size_t region,
-                                             unsigned long long* __restrict__ block_stats, int leave_k, const TraceLds<KD>& lds) {
+                                             unsigned long long* __restrict__ block_stats, int leave_k_and_refill, const TraceLds<KD>& lds) {
     constexpr int LDS_STACK = LdsStack<KD>::ENTRIES;
     float4* const lds_nodes = lds.nodes;
     unsigned int* const s_stat = lds.stat;
@@ -257,7 +257,8 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     float miss_scale = 1.0f;  // the ray's factor on the environment radiance (ray_o.w), handed on in a miss record
     bool fast_ok = false;
     bool drained = false;  // wave-uniform: the region has no unassigned ray left
-    const int refill_min = DYNAMIC ? 16 : 64;
+    const int refill_min = DYNAMIC ? ((leave_k_and_refill >> 8) ? (leave_k_and_refill >> 8) : 16) : 64;
+    const int leave_k = leave_k_and_refill & 0xff;
 
     // Takes the next deferred child; when none is left the ray is finished and its record written.
     auto pop_or_finish = [&]() {

@@ -75,7 +75,10 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
     // (measurement), bits 4..7 = leave_k of the node phase (0 = run it until nobody walks)
     const bool recip = (mode & 1) != 0;
     const bool dynamic = (mode & 4) == 0;
-    const int leave_k = (mode >> 4) & 15;
+    // the refill threshold rides above leave_k; unset, a scene walked entirely in LDS waits for half a wave
+    // (short walks: fuller refills pay), any other for a quarter (long walks: idle lanes cost more)
+    const int refill = (mode >> 8) & 127 ? (mode >> 8) & 127 : (fits_lds(scene) ? 32 : 16);
+    const int leave_k = ((mode >> 4) & 15) | (refill << 8);
 #define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats, leave_k
     if (dynamic) {
         if (recip) launch_variant<KD, COUNT, SLAB_RECIP, true>(PT_ARGS);

@@ -25,18 +25,18 @@ def test_every_traversal_setting_gives_the_oracle_hits(gpu_device, obj, accel):
     rays = np.concatenate([rays, extra])
     ref = o.trace(rays)
     s = load_gpu_scene(obj, accel)
-    for mode in (0x00, 0x01, 0x04, 0x05, 0x21, 0x41, 0xF1):
+    for mode in (0x00, 0x01, 0x04, 0x05, 0x21, 0x41, 0xF1, 0x2041, 0x0841, 0x4040):
         s.set_option(pta.OPT_TRAVERSAL, mode)
         got = s.intersect(rays)
         assert np.array_equal(got["tri"], ref["tri"]), hex(mode)
         assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32)), hex(mode)
         assert np.array_equal(got["bary"].view(np.uint32), ref["bary"].view(np.uint32)), hex(mode)
-    assert s.get_option(pta.OPT_TRAVERSAL) == 0xF1
+    assert s.get_option(pta.OPT_TRAVERSAL) == 0x4040
 
 
 def test_traversal_settings_give_the_same_image(gpu_device):
     imgs = []
-    for mode in (0x00, 0x41):
+    for mode in (0x00, 0x41, 0x2041):
         s = load_gpu_scene("cornellbox.obj", pta.BVH)
         s.set_option(pta.OPT_TRAVERSAL, mode)
         s.set_resolution(96, 72)
