@@ -63,12 +63,14 @@ enum {
                                * outgrows it adds nothing and is rendered again in halves at the next
                                * pt_synchronize / pt_download / pt_get_counters (PT_CNT_REPAIRED) */
     PT_OPT_LDS_NODES = 7,     /* tree nodes staged in LDS by the trace kernels (0 = none) */
-    PT_OPT_TRAVERSAL = 8,     /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab quotients from
-                                 the per-ray reciprocal plus one exact correction step instead of the division
-                                 sequence (default on); bits 4..7: k of the node phase's early leave rule (default 4,
-                                 0 = none); bit 2: refill a wave only when all its lanes are idle (measurement);
-                                 bits 8..14: idle lanes a wave waits for before it fetches new rays (0, the default: 32 for a
-                                 scene held entirely in LDS, else 16) */
+    PT_OPT_TRAVERSAL = 8,     /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab and triangle
+                                 quotients from an exact reciprocal plus one exact correction step instead of the
+                                 division sequence (default on); bit 2: refill a wave only when all its lanes are idle
+                                 (measurement); bits 4..7: k of the node phase's early-leave rule (leave when the lanes
+                                 on interior nodes number less than 1/k of those waiting at a leaf; 0, the default:
+                                 4 for a scene held entirely in LDS, else 1; 15 = never leave early); bits 8..14: idle
+                                 lanes a wave waits for before it fetches new rays (0, the default: 32 for a scene held
+                                 entirely in LDS, else 8) */
     PT_OPT_TAIL_LEVEL = 9,    /* bounce levels from this one on are finished by one fused launch in which every
                                  workgroup alternates trace and shade on its own queue region (default 6, the level
                                  after Russian roulette starts, src/cs488.h:2153; 0 = one launch per level and stage).

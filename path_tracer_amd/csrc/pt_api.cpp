@@ -83,7 +83,7 @@ struct PtContext {
     // options
     uint64_t seed = 0xcafef00dd15ea5e5ull;
     int max_level = 15;
-    int count_tests = 0, profile = 0, traversal = 0x41;  // reciprocal-form slab test, leave_k = 4, refill threshold chosen per scene
+    int count_tests = 0, profile = 0, traversal = 0x01;  // reciprocal-form slab test; leave rule and refill threshold chosen per scene
     size_t max_batch = (size_t)1 << 24;
     int queue_factor = 4;
     int lds_nodes_opt = 256;

@@ -69,9 +69,12 @@ hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchG
                        unsigned long long* block_stats) {
     const bool recip = (mode & 1) != 0;
     // the refill threshold rides above leave_k; unset, a scene walked entirely in LDS waits for half a wave
-    // (short walks: fuller refills pay), any other for a quarter (long walks: idle lanes cost more)
-    const int refill = (mode >> 8) & 127 ? (mode >> 8) & 127 : (fits_lds(scene) ? 32 : 16);
-    const int leave_k = ((mode >> 4) & 15) | (refill << 8);
+    // (short walks: fuller refills pay), any other for eight lanes (long walks: idle lanes cost more)
+    const int refill = (mode >> 8) & 127 ? (mode >> 8) & 127 : (fits_lds(scene) ? 32 : 8);
+    // node-phase leave rule: 0 = per scene (4 in LDS, else 1), 15 = stay until nobody walks
+    const int k_bits = (mode >> 4) & 15;
+    const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 0 : k_bits);
+    const int leave_k = k | (refill << 8);
 #define PT_ARGS cfg, scene, batch, level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k
     if (kd) {
         if (recip) launch_tail_variant<true, SLAB_RECIP>(PT_ARGS); else launch_tail_variant<true, SLAB_DIVIDE>(PT_ARGS);

@@ -72,13 +72,16 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
                     float4* hit, const int* n_rays, int n_fixed, int grid_blocks, int cap_block,
                     unsigned long long* block_stats) {
     // mode: bit 0 = reciprocal-form slab test, bit 2 = refill only when the whole wave is idle
-    // (measurement), bits 4..7 = leave_k of the node phase (0 = run it until nobody walks)
+    // (measurement), bits 4..7 = leave_k of the node phase, bits 8..14 = refill threshold (0 = chosen per scene)
     const bool recip = (mode & 1) != 0;
     const bool dynamic = (mode & 4) == 0;
     // the refill threshold rides above leave_k; unset, a scene walked entirely in LDS waits for half a wave
-    // (short walks: fuller refills pay), any other for a quarter (long walks: idle lanes cost more)
-    const int refill = (mode >> 8) & 127 ? (mode >> 8) & 127 : (fits_lds(scene) ? 32 : 16);
-    const int leave_k = ((mode >> 4) & 15) | (refill << 8);
+    // (short walks: fuller refills pay), any other for eight lanes (long walks: idle lanes cost more)
+    const int refill = (mode >> 8) & 127 ? (mode >> 8) & 127 : (fits_lds(scene) ? 32 : 8);
+    // node-phase leave rule: 0 = per scene (4 in LDS, else 1), 15 = stay until nobody walks
+    const int k_bits = (mode >> 4) & 15;
+    const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 0 : k_bits);
+    const int leave_k = k | (refill << 8);
 #define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats, leave_k
     if (dynamic) {
         if (recip) launch_variant<KD, COUNT, SLAB_RECIP, true>(PT_ARGS);
