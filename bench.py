@@ -132,6 +132,8 @@ def make_scene(pta, args, device, accel):
         s.set_option(pta.OPT_TRAVERSAL, args.traversal)
     if args.tail_level is not None:
         s.set_option(pta.OPT_TAIL_LEVEL, args.tail_level)
+    if args.blocks_per_cu is not None:
+        s.set_option(pta.OPT_BLOCKS_PER_CU, args.blocks_per_cu)
     s.set_resolution(args.width, args.height)
     return s
 
@@ -205,6 +207,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per frame and per GPU")
     ap.add_argument("--lds-nodes", type=int, default=None, help="tree nodes staged in LDS by the trace kernel (PT_OPT_LDS_NODES)")
+    ap.add_argument("--blocks-per-cu", type=int, default=None, help="PT_OPT_BLOCKS_PER_CU")
     ap.add_argument("--tail-level", type=int, default=None, help="PT_OPT_TAIL_LEVEL (0 = one launch per level)")
     ap.add_argument("--traversal", type=lambda v: int(v, 0), default=None, help="PT_OPT_TRAVERSAL bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -78,9 +78,11 @@ enum {
     PT_OPT_BUILD_THREADS = 10,/* host threads pt_build may use for the tree (0 = all, default; 1 = none extra).  Large
                                  subtrees near the root are built concurrently and spliced in at their sequential
                                  positions: the tree is the same for every value */
-    PT_OPT_OBJ_EXTENDED = 11  /* 1: pt_load_obj also accepts what the reference's reader does not (src/cs488.h:1059 reads
+    PT_OPT_OBJ_EXTENDED = 11, /* 1: pt_load_obj also accepts what the reference's reader does not (src/cs488.h:1059 reads
                                  three vertices per face, :944-946 positive indices only): polygons as triangle fans,
                                  negative indices, face lines of any length.  Default 0 = the reference's behaviour */
+    PT_OPT_BLOCKS_PER_CU = 12 /* workgroups (queue regions) per compute unit a batch is split over, 1..8; 0 = chosen per
+                                 scene so that one launch of the trace kernel is resident at once */
 };
 
 /* Counter indices for pt_get_counters (all cumulative since pt_reset_counters). */

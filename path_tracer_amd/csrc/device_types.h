@@ -124,6 +124,7 @@ hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
                         int* qcount_out);
+int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode);
 hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int kd, int mode, int level0, int levels,
                        int max_level, QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount,
                        unsigned long long* block_stats);

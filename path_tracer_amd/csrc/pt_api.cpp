@@ -64,7 +64,9 @@ struct PtContext {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int blocks = 2048;
+    int blocks = 2048;       // most workgroups a batch is ever split over (sizes the per-workgroup buffers)
+    int cus = 256;
+    int blocks_per_cu = 0;   // workgroups per CU a batch is split over; 0 = what the trace kernel keeps resident
     std::string error;
 
     // host scene
@@ -411,7 +413,9 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     b.n_slots = n_pixels * chunk;
     // workgroups sharing the batch: about 2048 camera samples each, at most the resident grid
     int nb = (b.n_slots + 2047) / 2048;
-    nb = nb < 1 ? 1 : (nb > c->blocks ? c->blocks : nb);
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : trace_resident_blocks_per_cu(c->scene, c->accel == PT_ACCEL_KD, c->traversal);
+    const int most = c->cus * per_cu;
+    nb = nb < 1 ? 1 : (nb > most ? most : nb);
     b.blocks = nb;
     b.slots_block = (((b.n_slots + 63) / 64 + nb - 1) / nb) * 64;  // runs of 64 samples dealt in rounds
     b.deal_shift = nb > 2 ? ((int)(nb * 0.6180339887) | 1) : 0;
@@ -570,7 +574,7 @@ int pt_create(int device, PtContext** out) {
     c->own_stream = true;
     hipDeviceProp_t prop;
     // eight 256-lane workgroups per CU are resident at once with the kernels' register and LDS use
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->blocks = prop.multiProcessorCount * 8;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) { c->cus = prop.multiProcessorCount; c->blocks = prop.multiProcessorCount * 8; }
     if (c->d_totals.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         c->d_batch_flags.ensure(FLAG_RING) != hipSuccess || hipMemset(c->d_batch_flags.ptr, 0, FLAG_RING * sizeof(int)) != hipSuccess ||
         c->d_block_stats.ensure((size_t)c->blocks * DC_BLOCK_COUNT) != hipSuccess ||
@@ -636,6 +640,9 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             break;
         case PT_OPT_TRAVERSAL: c->traversal = (int)value; break;
         case PT_OPT_OBJ_EXTENDED: c->obj_extended = value != 0; break;
+        case PT_OPT_BLOCKS_PER_CU:
+            if (value > 8) return fail(c, PT_ERR_INVALID_ARG, "at most 8 workgroups per CU");
+            c->blocks_per_cu = (int)value; break;
         case PT_OPT_BUILD_THREADS:
             if (value > 256) return fail(c, PT_ERR_INVALID_ARG, "more than 256 builder threads");
             c->build_threads = (int)value; break;
@@ -661,6 +668,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
         case PT_OPT_TAIL_LEVEL: *value = (uint64_t)c->tail_level; break;
         case PT_OPT_BUILD_THREADS: *value = (uint64_t)c->build_threads; break;
         case PT_OPT_OBJ_EXTENDED: *value = (uint64_t)c->obj_extended; break;
+        case PT_OPT_BLOCKS_PER_CU: *value = (uint64_t)c->blocks_per_cu; break;
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
     return PT_OK;

@@ -108,6 +108,28 @@ hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int
     return hipGetLastError();
 }
 
+namespace {
+template <bool KD, int SLAB>
+int resident_of(const SceneGpu& scene) {
+    int n = 0;
+    const size_t lds = dynamic_lds_bytes(scene);
+    const hipError_t e = fits_lds(scene)
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<KD, false, SLAB, true, true>, 256, lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<KD, false, SLAB, true, false>, 256, lds);
+    return e == hipSuccess ? n : 0;
+}
+}  // namespace
+
+// Workgroups of the trace kernel one CU holds at a time for this scene (registers and LDS).  A batch
+// split over exactly that many regions per CU runs every trace launch as one resident round; with
+// more regions than that the last, partly filled round costs as much as a full one.
+int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode) {
+    const bool recip = (mode & 1) != 0;
+    int n = kd ? (recip ? resident_of<true, SLAB_RECIP>(scene) : resident_of<true, SLAB_DIVIDE>(scene))
+               : (recip ? resident_of<false, SLAB_RECIP>(scene) : resident_of<false, SLAB_DIVIDE>(scene));
+    return n < 1 ? 8 : (n > 8 ? 8 : n);
+}
+
 hipError_t launch_pack_rays(const LaunchCfg& cfg, const float* rays6, int n, float4* ray_o, float4* ray_d) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(pack_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, cfg.stream, rays6, n, ray_o, ray_d);
