@@ -91,7 +91,7 @@ struct PtContext {
     int lds_nodes_opt = 256;
     int obj_extended = 0;   // pt_load_obj also takes polygons and negative indices
     int build_threads = 0;  // host threads of the tree builders, 0 = all
-    int tail_level = 6;  // levels from here on run in the fused kernel; Russian roulette starts at level 5 (src/cs488.h:2153)
+    int tail_level = 255;  // levels from here on run in the fused kernel; 255 = per scene (6 or 8), 0 = never
 
     // device scene
     DeviceBuffer<float4> d_nodes, d_isect, d_tri_pos, d_tri_nrm, d_mats;
@@ -438,8 +438,12 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     }
     // the deep, sparsely populated levels run in one fused launch (not while tests are counted or
     // the static refill is being measured: those are properties of the per-level kernels)
-    const bool fuse = c->tail_level > 0 && c->tail_level < levels && !c->count_tests && (c->traversal & 4) == 0;
-    const int split = fuse ? c->tail_level : levels;
+    // Russian roulette starts at level 5 (src/cs488.h:2153); a scene walked in LDS is handed over one level later,
+    // any other when its levels have thinned out further (the fused kernel keeps fewer waves resident, which
+    // shows where node fetches come from memory)
+    const int tail = c->tail_level == 255 ? (c->scene.lds_nodes >= c->scene.n_nodes ? 6 : 8) : c->tail_level;
+    const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
+    const int split = fuse ? tail : levels;
     for (int level = 0; level < split; level++) {
         const QueueSet& in = q[level & 1];
         const QueueSet& out = q[(level + 1) & 1];
@@ -647,7 +651,7 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             if (value > 256) return fail(c, PT_ERR_INVALID_ARG, "more than 256 builder threads");
             c->build_threads = (int)value; break;
         case PT_OPT_TAIL_LEVEL:
-            if (value > 64) return fail(c, PT_ERR_INVALID_ARG, "tail level above 64");
+            if (value > 64 && value != 255) return fail(c, PT_ERR_INVALID_ARG, "tail level above 64");
             c->tail_level = (int)value; break;
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
