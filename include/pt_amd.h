@@ -62,7 +62,9 @@ enum {
     PT_OPT_QUEUE_FACTOR = 6,  /* queue capacity = factor x batch (forked paths), default 4; a batch that
                                * outgrows it adds nothing and is rendered again in halves at the next
                                * pt_synchronize / pt_download / pt_get_counters (PT_CNT_REPAIRED) */
-    PT_OPT_LDS_NODES = 7,     /* tree nodes staged in LDS by the trace kernels (0 = none) */
+    PT_OPT_LDS_NODES = 7,     /* tree nodes staged in LDS by the trace kernels (0 = none; 65535, the default = the
+                                 largest of 256/128/64/0 that leaves five workgroups resident per CU).  Reads back as
+                                 the number in use once the tree is built */
     PT_OPT_TRAVERSAL = 8,     /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab and triangle
                                  quotients from an exact reciprocal plus one exact correction step instead of the
                                  division sequence (default on); bit 2: refill a wave only when all its lanes are idle

@@ -88,7 +88,8 @@ struct PtContext {
     int count_tests = 0, profile = 0, traversal = 0x01;  // reciprocal-form slab test; leave rule and refill threshold chosen per scene
     size_t max_batch = (size_t)1 << 24;
     int queue_factor = 4;
-    int lds_nodes_opt = 256;
+    int lds_nodes_opt = -1;  // tree nodes staged in LDS; -1 = chosen per scene
+    size_t kd_inline_refs = (size_t)1 << 24;  // kd-trees with more leaf references (1 GiB of records) keep one record per triangle behind index leaves
     int obj_extended = 0;   // pt_load_obj also takes polygons and negative indices
     int build_threads = 0;  // host threads of the tree builders, 0 = all
     int tail_level = 255;  // levels from here on run in the fused kernel; 255 = per scene (6 or 8), 0 = never
@@ -125,6 +126,8 @@ struct PtContext {
 };
 
 namespace {
+
+void choose_lds_nodes(PtContext* c);
 
 int fail(PtContext* c, int code, const std::string& msg) {
     if (c) c->error = msg;
@@ -244,11 +247,13 @@ int flatten_and_upload(PtContext* c) {
         out.push_back(make_float4(b.x, b.y, b.z, 0.0f));
         out.push_back(make_float4(ab.x, ab.y, ab.z, 0.0f));
     };
-    // kd-tree leaves repeat triangles; their records are stored per leaf only while that stays small
-    // enough to live in the caches (64 bytes a reference), otherwise once per triangle behind `refs`
+    // kd-tree leaves repeat triangles; their records are stored per leaf (64 bytes a reference: a leaf
+    // is one contiguous run, which measured 23 % faster than index leaves on a 1.4 M-reference tree
+    // although it is seven times the bytes) unless that takes more than 1 GiB, and once per triangle
+    // behind `refs` then
     // -- and also for a mesh small enough that the whole tree is staged in LDS, where a leaf
     // reference then costs 4 bytes instead of 64
-    const bool kd = t.kind == 1 && (t.refs.size() > 32768 || hm.num_tris() <= 256);
+    const bool kd = t.kind == 1 && (t.refs.size() > c->kd_inline_refs || hm.num_tris() <= 256);
     std::vector<int> refs;
     std::vector<float4> isect;
     if (kd) {
@@ -343,11 +348,11 @@ int flatten_and_upload(PtContext* c) {
     for (int k = 0; k < 3; k++) { s.root_lo[k] = t.nodes[0].box[k]; s.root_hi[k] = t.nodes[0].box[3 + k]; }
     s.root_ref = root_ref;
     s.n_nodes = (int)order.size();
-    s.lds_nodes = c->lds_nodes_opt < s.n_nodes ? c->lds_nodes_opt : s.n_nodes;
     s.n_tris = nt;
     s.leaf_inline = kd ? 0 : 1;
     s.n_records = (int)(isect.size() / 4);
     s.n_refs = (int)refs.size();
+    choose_lds_nodes(c);
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)
         for (int k = 0; k < 6; k++)
@@ -374,6 +379,27 @@ void camera_of(PtContext* c, CameraGpu& cam) {
     cam.film = c->film;
     cam.dist = c->film / (2.0f * tanf(c->fov * deg_to_rad * 0.5f));
     cam.width = c->width; cam.height = c->height;
+}
+
+// How many of the top tree nodes the trace kernels stage in LDS.  Unless set explicitly: the
+// largest of 256 / 128 / 64 / 0 with which a CU still holds five workgroups of the trace kernel
+// (a kd-tree's LDS stack is wider, so it gets fewer nodes); staging more trades resident waves,
+// which hide the latency of the node fetches that stay in memory, for fewer such fetches.
+void choose_lds_nodes(PtContext* c) {
+    SceneGpu& s = c->scene;
+    if (c->lds_nodes_opt >= 0) {
+        s.lds_nodes = c->lds_nodes_opt < s.n_nodes ? c->lds_nodes_opt : s.n_nodes;
+        return;
+    }
+    const int candidates[4] = {256, 128, 64, 0};
+    int best = 0, best_resident = -1;
+    for (int cand : candidates) {
+        s.lds_nodes = cand < s.n_nodes ? cand : s.n_nodes;
+        const int resident = trace_resident_blocks_per_cu(s, c->accel == PT_ACCEL_KD, c->traversal);
+        if (resident >= 5) return;
+        if (resident > best_resident) { best_resident = resident; best = s.lds_nodes; }
+    }
+    s.lds_nodes = best;
 }
 
 int ensure_queues(PtContext* c, size_t batch) {
@@ -638,9 +664,9 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             if (value < 2 || value > 64) return fail(c, PT_ERR_INVALID_ARG, "queue factor out of range");
             c->queue_factor = (int)value; c->batch_alloc = 0; break;
         case PT_OPT_LDS_NODES:
-            if (value > 2048) return fail(c, PT_ERR_INVALID_ARG, "at most 2048 nodes fit the LDS stage");
-            c->lds_nodes_opt = (int)value;
-            c->scene.lds_nodes = c->lds_nodes_opt < c->scene.n_nodes ? c->lds_nodes_opt : c->scene.n_nodes;
+            if (value > 2048 && value != 65535) return fail(c, PT_ERR_INVALID_ARG, "at most 2048 nodes fit the LDS stage");
+            c->lds_nodes_opt = value == 65535 ? -1 : (int)value;
+            if (c->built) choose_lds_nodes(c);
             break;
         case PT_OPT_TRAVERSAL: c->traversal = (int)value; break;
         case PT_OPT_OBJ_EXTENDED: c->obj_extended = value != 0; break;
@@ -667,7 +693,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
         case PT_OPT_PROFILE: *value = (uint64_t)c->profile; break;
         case PT_OPT_MAX_BATCH: *value = (uint64_t)c->max_batch; break;
         case PT_OPT_QUEUE_FACTOR: *value = (uint64_t)c->queue_factor; break;
-        case PT_OPT_LDS_NODES: *value = (uint64_t)c->lds_nodes_opt; break;
+        case PT_OPT_LDS_NODES: *value = c->built ? (uint64_t)c->scene.lds_nodes : (c->lds_nodes_opt < 0 ? 65535u : (uint64_t)c->lds_nodes_opt); break;
         case PT_OPT_TRAVERSAL: *value = (uint64_t)c->traversal; break;
         case PT_OPT_TAIL_LEVEL: *value = (uint64_t)c->tail_level; break;
         case PT_OPT_BUILD_THREADS: *value = (uint64_t)c->build_threads; break;
