@@ -137,3 +137,79 @@ def test_bounce_populations_parity(gpu_device, obj, accel):
         if len(rays) == 0:
             break
     assert total > 50000
+
+
+def tie_heavy_mesh(seed=23):
+    """Geometry built to produce exact ties and degenerate cases: a grid of coplanar triangles sharing every
+    edge and vertex, each cell's triangles stored two or three times under different indices, a second
+    coplanar layer shifted by half a cell (overlapping, same plane), zero-area and repeated-vertex
+    triangles, a few slivers, and one far outlier that stretches the root box."""
+    rng = np.random.default_rng(seed)
+    tris = []
+    n = 14
+    xs = np.linspace(-1, 1, n + 1, dtype=np.float32)
+    for i in range(n):
+        for j in range(n):
+            a = [xs[i], xs[j], 0.0]; b = [xs[i + 1], xs[j], 0.0]; c = [xs[i + 1], xs[j + 1], 0.0]; d = [xs[i], xs[j + 1], 0.0]
+            for _ in range(int(rng.integers(1, 4))):          # duplicates: same triangles, different ids
+                tris += [[a, b, c], [a, c, d]]
+            if (i + j) % 3 == 0:                               # overlapping coplanar layer, shifted
+                h = float(xs[1] - xs[0]) / 2
+                tris.append([[a[0] + h, a[1] + h, 0.0], [b[0] + h, b[1] + h, 0.0], [c[0] + h, c[1] + h, 0.0]])
+    for _ in range(40):                                        # zero area: repeated vertex / collinear
+        p = (rng.random(3) * 2 - 1).tolist(); q = (rng.random(3) * 2 - 1).tolist()
+        tris.append([p, p, q])
+        tris.append([p, q, [(p[k] + q[k]) / 2 for k in range(3)]])
+    for _ in range(40):                                        # slivers
+        p = rng.random(3) * 2 - 1
+        tris.append([p.tolist(), (p + [1.5, 1e-6, 0]).tolist(), (p + [0.7, 0, 1e-6]).tolist()])
+    tris.append([[50, 50, 50], [51, 50, 50], [50, 51, 50]])
+    # a second, tilted wall of shared-edge triangles behind the first
+    for i in range(n):
+        for j in range(n):
+            z = lambda x, y: -0.5 + 0.25 * x
+            a = [xs[i], xs[j]]; b = [xs[i + 1], xs[j]]; c = [xs[i + 1], xs[j + 1]]; d = [xs[i], xs[j + 1]]
+            tris += [[a + [z(*a)], b + [z(*b)], c + [z(*c)]], [a + [z(*a)], c + [z(*c)], d + [z(*d)]]]
+    pos = np.asarray(tris, np.float32).reshape(-1, 9)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (pos.shape[0], 3)).reshape(-1, 9)
+    return pos, nrm
+
+
+@pytest.mark.parametrize("accel", [orc.BVH, orc.KD])
+def test_exact_ties_resolve_to_the_oracle_winner(gpu_device, accel):
+    """With duplicated and overlapping coplanar triangles most rays see several triangles at the identical
+    distance; the reference keeps the first one its traversal visits (strict <, src/cs488.h:1677-1681,
+    1350-1354).  The winner's index must be the oracle's for every ray, which pins the visiting order."""
+    import path_tracer_amd as pta
+    pos, nrm = tie_heavy_mesh()
+    o = orc.Oracle()
+    o.set_tris(pos, nrm)
+    o.build(accel)
+    s = pta.Scene(0)
+    s.set_mesh(pos, nrm)
+    s.pre_calc(accel)
+    rng = np.random.default_rng(5)
+    # rays through grid vertices, edge midpoints and cell interiors of the z = 0 layer, from both sides
+    n = 14
+    xs = np.linspace(-1, 1, 2 * n + 1)
+    gx, gy = np.meshgrid(xs, xs)
+    targets = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1)
+    targets = np.concatenate([targets, np.stack([rng.random(3000) * 2 - 1, rng.random(3000) * 2 - 1, np.zeros(3000)], 1)])
+    rays = []
+    for eye in ([0.1, -0.2, 2.0], [0.0, 0.0, 3.0], [0.3, 0.4, -2.5], [-1.7, 0.2, 1.1]):
+        d = targets - np.asarray(eye)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays.append(np.concatenate([np.broadcast_to(np.asarray(eye, np.float64), d.shape), d], 1))
+    # axis-parallel rays straight down the grid lines
+    down = np.concatenate([targets[:, :2], np.full((len(targets), 1), 1.5), np.zeros((len(targets), 2)), -np.ones((len(targets), 1))], 1)
+    rays = np.concatenate(rays + [down]).astype(np.float32)
+    ref = o.trace(rays)
+    got = s.intersect(rays)
+    assert np.array_equal(got["tri"], ref["tri"])
+    assert np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    hit = ref["tri"] >= 0
+    assert np.array_equal(got["bary"][hit].view(np.uint32), ref["bary"][hit].view(np.uint32))
+    # the test is only meaningful if ties are common: count rays whose winner shares its distance
+    tied = sum(1 for i in rng.choice(np.nonzero(hit)[0], 300, replace=False) if len(o.tie_set(rays[i], ref["t"][i])) > 1)
+    assert tied > 100, tied
+    check_batch(o, s, ray_batch(pos, n_random=4000, n_vertex=800, seed=9))
