@@ -105,3 +105,41 @@ def test_batching_and_split_are_invisible(gpu_device):
     both = a.accumulation_buffer() + b.accumulation_buffer()
     assert np.allclose(whole, both, rtol=2e-5, atol=1e-6)
     assert a.total_samples() == 6
+
+
+def test_full_size_frame_properties(gpu_device):
+    """The benchmark's frame (cornellbox, 1024 x 1024, 10 spp) is too large for the oracle to repeat in a
+    test, so it is checked through properties that do not depend on size: the same samples in smaller
+    batches and as a two-way sample split give the same accumulation buffer (bit for bit: no two paths of
+    this scene share a sample), the ray count matches, frame = accumulation / total, and the mean radiance
+    agrees with an oracle render of the same view at 192 x 192."""
+    import path_tracer_amd as pta
+    W = H = 1024
+    s = load_gpu_scene("cornellbox.obj", orc.BVH)
+    s.set_resolution(W, H)
+    s.pathtrace(10)
+    whole = s.accumulation_buffer()
+    c_whole = s.counters()
+    assert c_whole[pta.CNT_SAMPLES] == W * H * 10 and c_whole[pta.CNT_NAN_SAMPLES] == 0
+    assert np.allclose(s.frame_buffer(), whole / 10.0, rtol=1e-6, atol=0)
+
+    t = load_gpu_scene("cornellbox.obj", orc.BVH)
+    t.set_option(pta.OPT_MAX_BATCH, 3 << 20)   # three samples of the image per batch
+    t.set_resolution(W, H)
+    t.pathtrace(10)
+    assert np.array_equal(t.accumulation_buffer(), whole)
+    assert t.counters()[pta.CNT_RAYS] == c_whole[pta.CNT_RAYS]
+
+    a = load_gpu_scene("cornellbox.obj", orc.BVH)
+    b = load_gpu_scene("cornellbox.obj", orc.BVH)
+    for x, (first, count) in ((a, (0, 5)), (b, (5, 5))):
+        x.set_resolution(W, H)
+        x.pathtrace_split(10, first, count)
+    # each half is summed in sample order from zero, so only the final addition differs in rounding
+    assert np.allclose(a.accumulation_buffer() + b.accumulation_buffer(), whole, rtol=1e-6, atol=1e-7)
+
+    o = load_oracle_scene("cornellbox.obj", orc.BVH)
+    o.reset(192, 192)
+    o.render(spp=40, frames=1, threads=8)
+    ref = o.image()
+    assert abs(whole.mean() / 10.0 - ref.mean()) < 0.01 * ref.mean()
