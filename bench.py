@@ -10,7 +10,10 @@ With N > 1 (one process per GPU, launched by torch.distributed.run) every rank r
 `spp` samples of a frame that adds N*spp samples per pixel (sample split, weak scaling) and the
 per-frame accumulation buffers are summed onto rank 0 with one RCCL reduce.
 
-Prints one JSON line on rank 0; see README / DESIGN.md for the fields.
+Prints one JSON line on rank 0: metric / value (closest-hit queries per second, whole job), spp_per_s,
+ms_per_step, `roofline` for the dominant kernel (algorithmic bytes per launch over the launch time measured
+with HIP events, committed counter figures for HBM traffic and VALU use), per-stage milliseconds, a short
+kd-tree run, and `cpu_baseline` (the CPU oracle timed on this host, rank 0 at N = 1 only).
 """
 import argparse
 import json
