@@ -7,7 +7,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):  # run as: python tests/exp_trace_modes.py
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402
 import orc  # noqa: E402
