@@ -352,6 +352,9 @@ int flatten_and_upload(PtContext* c) {
     s.leaf_inline = kd ? 0 : 1;
     s.n_records = (int)(isect.size() / 4);
     s.n_refs = (int)refs.size();
+    s.plain_shading = c->env.h == 0 ? 1 : 0;
+    for (const HostMaterial& hm2 : m.materials)
+        if (hm2.type != MAT_LAMBERTIAN || hm2.textured || !(hm2.opacity >= 1.0f - PT_EPSILON)) s.plain_shading = 0;
     choose_lds_nodes(c);
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)

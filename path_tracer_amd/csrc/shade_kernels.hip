@@ -65,6 +65,7 @@ __global__ void sample_keys_kernel(uint64_t seed, int sample0, int chunk, uint64
 }
 
 // ---- one bounce of shading for every path in the queue ----
+template <bool PLAIN>
 __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int level, int max_level, QueueSet in,
                                                     const float4* __restrict__ hit, QueueSet out,
                                                     float4* __restrict__ sample_rad, const int* __restrict__ qcount_in,
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
         if (threadIdx.x == 0) qcount_out[blk] = 0;
         return;
     }
-    const int produced = shade_region(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
+    const int produced = shade_region<PLAIN>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
     if (threadIdx.x == 0) qcount_out[blk] = produced;
 }
 
@@ -158,8 +159,12 @@ hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const Batch
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
                         int* qcount_out) {
-    hipLaunchKernelGGL(shade_kernel, dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit,
-                       out, sample_rad, qcount_in, qcount_out);
+    if (scene.plain_shading)
+        hipLaunchKernelGGL(shade_kernel<true>, dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit,
+                           out, sample_rad, qcount_in, qcount_out);
+    else
+        hipLaunchKernelGGL(shade_kernel<false>, dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit,
+                           out, sample_rad, qcount_in, qcount_out);
     return hipGetLastError();
 }
 
