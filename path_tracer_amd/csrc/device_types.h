@@ -63,7 +63,7 @@ struct SceneGpu {
     int leaf_inline;  // layout of the leaves, see above
     int n_records;    // intersection records in `isect`
     int n_refs;       // entries of `refs` (leaf_inline = 0)
-    int plain_shading; // only opaque untextured Lambertian materials and no environment image: the shading kernels drop every other branch
+    int shading_kind; // which instantiation of the shading code the scene needs (SHADE_ALL / _LAMBERTIAN / _PLAIN)
     int planes_ok;  // every box coordinate is 0 or at least 1e-17 in magnitude (reciprocal slab form allowed)
 };
 

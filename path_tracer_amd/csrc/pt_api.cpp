@@ -352,9 +352,12 @@ int flatten_and_upload(PtContext* c) {
     s.leaf_inline = kd ? 0 : 1;
     s.n_records = (int)(isect.size() / 4);
     s.n_refs = (int)refs.size();
-    s.plain_shading = c->env.h == 0 ? 1 : 0;
-    for (const HostMaterial& hm2 : m.materials)
-        if (hm2.type != MAT_LAMBERTIAN || hm2.textured || !(hm2.opacity >= 1.0f - PT_EPSILON)) s.plain_shading = 0;
+    bool lambertian = true, plain = c->env.h == 0;
+    for (const HostMaterial& hm2 : m.materials) {
+        if (hm2.type != MAT_LAMBERTIAN) lambertian = false;
+        if (hm2.textured || !(hm2.opacity >= 1.0f - PT_EPSILON)) plain = false;
+    }
+    s.shading_kind = !lambertian ? 0 : (plain ? 2 : 1);  // SHADE_ALL / SHADE_PLAIN / SHADE_LAMBERTIAN of shade_device.h
     choose_lds_nodes(c);
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)

@@ -225,10 +225,13 @@ __device__ __forceinline__ vec3 texel(const SceneGpu& sc, int tw, int th, int of
 // Called by all 256 threads of the workgroup.  Survivors go to the same region of `out`; the
 // number produced (clamped to the region's capacity) is returned to every thread, with a barrier
 // passed, and an overflow raises the batch's flag.
-// PLAIN: the host saw nothing but opaque, untextured Lambertian materials and no environment image,
-// so the metal, glass, unknown-type, texture, fork and environment branches (and the registers they
-// keep live) are compiled out.
-template <bool PLAIN>
+// What the host saw in the scene decides which instantiation runs, so that branches that cannot be
+// taken (and the registers they keep live) are compiled out:
+//   SHADE_PLAIN       only opaque, untextured Lambertian materials and no environment image
+//   SHADE_LAMBERTIAN  only Lambertian materials (textures, translucency and an environment allowed)
+//   SHADE_ALL         anything
+enum { SHADE_ALL = 0, SHADE_LAMBERTIAN = 1, SHADE_PLAIN = 2 };
+template <int KIND>
 __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& b, int level, int max_level, const QueueSet& in,
                                             const float4* __restrict__ hit, const QueueSet& out,
                                             float4* __restrict__ sample_rad, int n, int* s_out_ptr) {
@@ -258,7 +261,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
 
             if (tri < 0) {
                 // miss: environment radiance (zero without a probe; the product keeps a NaN alive)
-                if (PLAIN) {  // no environment: radiance zero, times a throughput that may be NaN
+                if (KIND == SHADE_PLAIN) {  // no environment: radiance zero, times a throughput that may be NaN
                     if (!finite3(beta)) add_radiance(sample_rad, slot, beta * 0.0f);
                 } else {
                     const vec3 e = env_lookup(sc, d) * h.z;  // miss record: h.z = the ray's miss scale
@@ -294,7 +297,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                 if (type == 0) {
                     const float4 m4 = mat[4];
                     colour = v3(m4.x, m4.y, m4.z);  // Kd / pi, divided on the host
-                    if (!PLAIN && tw > 0) {
+                    if (KIND != SHADE_PLAIN && tw > 0) {
                         const float2 T0 = sc.tri_uv[3 * tri], T1 = sc.tri_uv[3 * tri + 1], T2 = sc.tri_uv[3 * tri + 2];
                         const float tu = ha * T0.x + hb * T1.x + hg * T2.x;
                         const float tv = ha * T0.y + hb * T1.y + hg * T2.y;
@@ -319,7 +322,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                         ended = true;
                     } else {
                         const float p = div_by_recip(ct, PT_PI, 1.0f / PT_PI);
-                        const bool translucent = !PLAIN && opacity < 1.0f - PT_EPSILON;
+                        const bool translucent = KIND != SHADE_PLAIN && opacity < 1.0f - PT_EPSILON;
                         const vec3 weight = translucent ? beta * opacity : beta;
                         if (Ke.x != 0.0f || Ke.y != 0.0f || Ke.z != 0.0f) add_radiance(sample_rad, slot, weight * Ke);
                         emit0 = true;
@@ -334,7 +337,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                             b1 = beta * (1 - opacity);
                         }
                     }
-                } else if (!PLAIN && type == 1) {
+                } else if (KIND == SHADE_ALL && type == 1) {
                     const float ra = rng.next();
                     const float rb = rng.next();
                     const vec3 hv = half_vector(N, view, rough, ra, rb);
@@ -349,7 +352,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                         d0 = light;
                         b0 = beta * (Kd * ln + Ks * spec);
                     }
-                } else if (!PLAIN && type == 2) {
+                } else if (KIND == SHADE_ALL && type == 2) {
                     const vec3 wi = d;
                     const float wn = dot(wi, N);
                     const float e1 = backface ? eta : PT_ETA_AIR, e2 = backface ? PT_ETA_AIR : eta;
@@ -373,7 +376,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                         d0 = rdir;
                         o0 = P - PT_EPSILON * N;
                     }
-                } else if (!PLAIN) {
+                } else if (KIND == SHADE_ALL) {
                     // unknown material type: the reference's error colour (src/cs488.h:2170)
                     add_radiance(sample_rad, slot, beta * v3(100.0f, 0.0f, 100.0f));
                 }

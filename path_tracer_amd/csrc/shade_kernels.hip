@@ -65,7 +65,7 @@ __global__ void sample_keys_kernel(uint64_t seed, int sample0, int chunk, uint64
 }
 
 // ---- one bounce of shading for every path in the queue ----
-template <bool PLAIN>
+template <int KIND>
 __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int level, int max_level, QueueSet in,
                                                     const float4* __restrict__ hit, QueueSet out,
                                                     float4* __restrict__ sample_rad, const int* __restrict__ qcount_in,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
         if (threadIdx.x == 0) qcount_out[blk] = 0;
         return;
     }
-    const int produced = shade_region<PLAIN>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
+    const int produced = shade_region<KIND>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
     if (threadIdx.x == 0) qcount_out[blk] = produced;
 }
 
@@ -159,12 +159,13 @@ hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const Batch
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
                         int* qcount_out) {
-    if (scene.plain_shading)
-        hipLaunchKernelGGL(shade_kernel<true>, dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit,
-                           out, sample_rad, qcount_in, qcount_out);
-    else
-        hipLaunchKernelGGL(shade_kernel<false>, dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit,
-                           out, sample_rad, qcount_in, qcount_out);
+#define PT_SHADE(KIND)                                                                                                      \
+    hipLaunchKernelGGL(shade_kernel<KIND>, dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit, \
+                       out, sample_rad, qcount_in, qcount_out)
+    if (scene.shading_kind == SHADE_PLAIN) PT_SHADE(SHADE_PLAIN);
+    else if (scene.shading_kind == SHADE_LAMBERTIAN) PT_SHADE(SHADE_LAMBERTIAN);
+    else PT_SHADE(SHADE_ALL);
+#undef PT_SHADE
     return hipGetLastError();
 }
 

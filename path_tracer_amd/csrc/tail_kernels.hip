@@ -17,7 +17,7 @@ namespace {
 using namespace trace_dev;
 using namespace shade_dev;
 
-template <bool KD, int SLAB, bool ALL_LDS, bool PLAIN>
+template <bool KD, int SLAB, bool ALL_LDS, int KIND>
 __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int level0, int levels, int max_level, QueueSet qa,
                                                    QueueSet qb, float4* __restrict__ hit, float4* __restrict__ sample_rad,
                                                    int* __restrict__ qcount, unsigned long long* __restrict__ block_stats,
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int 
             const QueueSet& in = (level & 1) ? qb : qa;
             const QueueSet& out = (level & 1) ? qa : qb;
             trace_region<KD, false, SLAB, true, ALL_LDS>(sc, in.ray_o, in.ray_d, hit, n, region, block_stats, leave_k, lds);
-            n = shade_region<PLAIN>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
+            n = shade_region<KIND>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
             __syncthreads();  // s_out is rewritten by the next level's shading
         }
         if (threadIdx.x == 0) qcount[(size_t)(level + 1) * nb + blk] = n;  // the tally reads every level
@@ -52,14 +52,17 @@ void launch_tail_variant(const LaunchCfg& cfg, const SceneGpu& scene, const Batc
                          QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount, unsigned long long* block_stats,
                          int leave_k) {
     const size_t lds = dynamic_lds_bytes(scene);
-#define PT_TAIL(ALL, PLAIN_)                                                                                              \
-    hipLaunchKernelGGL((tail_kernel<KD, SLAB, ALL, PLAIN_>), dim3(batch.blocks), dim3(256), lds, cfg.stream, scene, batch, \
+#define PT_TAIL(ALL, KIND)                                                                                             \
+    hipLaunchKernelGGL((tail_kernel<KD, SLAB, ALL, KIND>), dim3(batch.blocks), dim3(256), lds, cfg.stream, scene, batch, \
                        level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k)
-    if (fits_lds(scene)) {
-        if (scene.plain_shading) PT_TAIL(true, true); else PT_TAIL(true, false);
-    } else {
-        if (scene.plain_shading) PT_TAIL(false, true); else PT_TAIL(false, false);
-    }
+#define PT_TAIL_KIND(ALL)                                                            \
+    do {                                                                             \
+        if (scene.shading_kind == SHADE_PLAIN) PT_TAIL(ALL, SHADE_PLAIN);            \
+        else if (scene.shading_kind == SHADE_LAMBERTIAN) PT_TAIL(ALL, SHADE_LAMBERTIAN); \
+        else PT_TAIL(ALL, SHADE_ALL);                                                \
+    } while (0)
+    if (fits_lds(scene)) PT_TAIL_KIND(true); else PT_TAIL_KIND(false);
+#undef PT_TAIL_KIND
 #undef PT_TAIL
 }
 
