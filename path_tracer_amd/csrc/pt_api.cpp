@@ -66,6 +66,7 @@ struct PtContext {
     bool own_stream = false;
     int blocks = 2048;       // most workgroups a batch is ever split over (sizes the per-workgroup buffers)
     int cus = 256;
+    int resident_per_cu = 0; // workgroups of the trace kernel a CU holds for the current scene and settings (0 = not asked yet)
     int blocks_per_cu = 0;   // workgroups per CU a batch is split over; 0 = what the trace kernel keeps resident
     std::string error;
 
@@ -393,6 +394,7 @@ void camera_of(PtContext* c, CameraGpu& cam) {
 // which hide the latency of the node fetches that stay in memory, for fewer such fetches.
 void choose_lds_nodes(PtContext* c) {
     SceneGpu& s = c->scene;
+    c->resident_per_cu = 0;
     if (c->lds_nodes_opt >= 0) {
         s.lds_nodes = c->lds_nodes_opt < s.n_nodes ? c->lds_nodes_opt : s.n_nodes;
         return;
@@ -445,7 +447,8 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     b.n_slots = n_pixels * chunk;
     // workgroups sharing the batch: about 2048 camera samples each, at most the resident grid
     int nb = (b.n_slots + 2047) / 2048;
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : trace_resident_blocks_per_cu(c->scene, c->accel == PT_ACCEL_KD, c->traversal);
+    if (c->resident_per_cu <= 0) c->resident_per_cu = trace_resident_blocks_per_cu(c->scene, c->accel == PT_ACCEL_KD, c->traversal);
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : c->resident_per_cu;
     const int most = c->cus * per_cu;
     nb = nb < 1 ? 1 : (nb > most ? most : nb);
     b.blocks = nb;
@@ -676,7 +679,7 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             c->lds_nodes_opt = value == 65535 ? -1 : (int)value;
             if (c->built) choose_lds_nodes(c);
             break;
-        case PT_OPT_TRAVERSAL: c->traversal = (int)value; break;
+        case PT_OPT_TRAVERSAL: c->traversal = (int)value; c->resident_per_cu = 0; break;
         case PT_OPT_OBJ_EXTENDED: c->obj_extended = value != 0; break;
         case PT_OPT_BLOCKS_PER_CU:
             if (value > 8) return fail(c, PT_ERR_INVALID_ARG, "at most 8 workgroups per CU");
