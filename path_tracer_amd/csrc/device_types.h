@@ -40,6 +40,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 
 namespace pt {
@@ -106,6 +107,9 @@ enum { TRACE_STACK = 64 };
 // Device counters (uint64 each).  `totals` holds one set (DC_COUNT words) written by the tally and
 // accumulate kernels; `block_stats` holds DC_BLOCK_COUNT words per workgroup, each updated only by
 // its own workgroup with plain loads and stores, and is summed on the host.
+// Child reference of a leaf without triangles (kd-trees have them): never entered by the walk.
+enum : int { EMPTY_LEAF = INT_MIN + 1 };
+
 enum { DC_RAYS = 0, DC_NAN = 1, DC_TAIL_RAYS = 2, DC_MAXQ = 3, DC_COUNT = 4 };
 enum { DB_HITS = 0, DB_BOX = 1, DB_TRI = 2, DB_OVERFLOW = 3, DC_BLOCK_COUNT = 4 };
 

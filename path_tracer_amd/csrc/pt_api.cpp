@@ -262,6 +262,9 @@ int flatten_and_upload(PtContext* c) {
     }
     auto leaf_reference = [&](int node) -> int {
         const HostTree::Node& nd = t.nodes[node];
+        // a kd-tree has leaves without triangles (src/cs488.h:1306-1311 stops on cost, not on emptiness);
+        // visiting one changes nothing, so the walk is told not to enter it
+        if (nd.count == 0 && node != 0) return EMPTY_LEAF;
         if (kd) {
             const int off = (int)refs.size();
             refs.push_back(nd.count);

@@ -149,7 +149,7 @@ struct NodeStep {
 };
 
 // The reference's decisions for one interior node (src/cs488.h:1684-1701, 1357-1375).
-template <bool RECIP>
+template <bool RECIP, bool KD>
 __device__ __forceinline__ void node_step(const float4& q0, const float4& q1, const float4& q2, const float4& q3,
                                           vec3 o, vec3 d, vec3 r, float best_t, NodeStep& st) {
     float tl, tr;
@@ -161,9 +161,13 @@ __device__ __forceinline__ void node_step(const float4& q0, const float4& q1, co
         hl = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, tl);
         hr = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, tr);
     }
+    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
     hl = hl && (tl < best_t);
     hr = hr && (tr < best_t);
-    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+    if (KD) {  // an empty leaf (kd-trees have them) holds nothing to test: entering it would change
+        hl = hl && left != EMPTY_LEAF;   // neither the hit nor the order of the rest
+        hr = hr && right != EMPTY_LEAF;
+    }
     st.push = hl && hr;
     st.descend = hl || hr;
     const bool left_first = hl && (!hr || (tl < tr));  // both: nearer first, right on ties; one: that one
@@ -337,8 +341,8 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 }
                 if (COUNT) n_box += 2;
                 NodeStep st;
-                if (SLAB == SLAB_RECIP && fast_ok) node_step<true>(q0, q1, q2, q3, o, d, inv, best.t, st);
-                else node_step<false>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                if (SLAB == SLAB_RECIP && fast_ok) node_step<true, KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                else node_step<false, KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
                 if (st.push) {
                     if (__builtin_expect(sp < LDS_STACK, 1)) {
                         s_stack[sp * 256 + tid] = st.deferred;
