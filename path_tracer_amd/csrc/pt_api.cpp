@@ -109,6 +109,7 @@ struct PtContext {
     DeviceBuffer<float4> q_ray_o[2], q_ray_d[2], q_beta[2], d_hit, d_sample_rad;
     DeviceBuffer<int> d_qcount;
     DeviceBuffer<unsigned long long> d_totals, d_block_stats;
+    DeviceBuffer<float4> d_eye;           // origin record shared by the camera rays of the batch in flight
     DeviceBuffer<uint64_t> d_keys;        // sampler keys of the batch in flight
     DeviceBuffer<int> d_batch_flags;      // FLAG_RING overflow flags, one per batch in flight
     std::vector<IssuedBatch> issued;      // batches whose flags have not been looked at yet
@@ -356,6 +357,7 @@ int flatten_and_upload(PtContext* c) {
     s.leaf_inline = kd ? 0 : 1;
     s.n_records = (int)(isect.size() / 4);
     s.n_refs = (int)refs.size();
+    s.shared_origin = 0;
     bool lambertian = true, plain = c->env.h == 0;
     for (const HostMaterial& hm2 : m.materials) {
         if (hm2.type != MAT_LAMBERTIAN) lambertian = false;
@@ -463,6 +465,7 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     rec.flag = (int)(c->batch_seq++ % FLAG_RING);
     b.overflow = c->d_batch_flags.ptr + rec.flag;
     PT_HIP(c, c->d_keys.ensure((size_t)(chunk > 1024 ? chunk : 1024)));
+    PT_HIP(c, c->d_eye.ensure(1));
     b.keys = c->d_keys.ptr;
     const LaunchCfg cfg = cfg_of(c);
     const int levels = c->max_level + 2;  // levels 0 .. maxLevel+1; the last one only resolves misses
@@ -470,9 +473,16 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     PT_HIP(c, c->d_qcount.ensure(((size_t)levels + 1) * (size_t)c->blocks));
     QueueSet q[2];
     for (int k = 0; k < 2; k++) { q[k].ray_o = c->q_ray_o[k].ptr; q[k].ray_d = c->q_ray_d[k].ptr; q[k].beta = c->q_beta[k].ptr; }
+    // camera rays are stored as directions only: one shared origin record, no throughputs
+    QueueSet camera_rays = q[0];
+    camera_rays.ray_o = c->d_eye.ptr;
+    camera_rays.beta = nullptr;
+    const SceneGpu& scene = c->scene;
+    SceneGpu scene0 = c->scene;
+    scene0.shared_origin = 1;
     {
         ScopedTimer tm(c, PT_TIMER_RAYGEN);
-        PT_HIP(c, launch_raygen(cfg, cam, b, q[0], c->d_sample_rad.ptr, c->d_qcount.ptr));
+        PT_HIP(c, launch_raygen(cfg, cam, b, camera_rays, c->d_sample_rad.ptr, c->d_qcount.ptr));
     }
     // the deep, sparsely populated levels run in one fused launch (not while tests are counted or
     // the static refill is being measured: those are properties of the per-level kernels)
@@ -485,22 +495,22 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
     const int split = fuse ? tail : levels;
     for (int level = 0; level < split; level++) {
-        const QueueSet& in = q[level & 1];
+        const QueueSet& in = level == 0 ? camera_rays : q[level & 1];
         const QueueSet& out = q[(level + 1) & 1];
         {
             ScopedTimer tm(c, PT_TIMER_TRACE);
-            PT_HIP(c, launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, in.ray_o, in.ray_d,
+            PT_HIP(c, launch_trace(cfg, level == 0 ? scene0 : scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, in.ray_o, in.ray_d,
                                    c->d_hit.ptr, c->d_qcount.ptr + (size_t)level * nb, 0, nb, b.cap_block, c->d_block_stats.ptr));
         }
         {
             ScopedTimer tm(c, PT_TIMER_SHADE);
-            PT_HIP(c, launch_shade(cfg, c->scene, b, level, c->max_level, in, c->d_hit.ptr, out, c->d_sample_rad.ptr,
+            PT_HIP(c, launch_shade(cfg, scene, b, level, c->max_level, in, c->d_hit.ptr, out, c->d_sample_rad.ptr,
                                    c->d_qcount.ptr + (size_t)level * nb, c->d_qcount.ptr + (size_t)(level + 1) * nb));
         }
     }
     if (fuse) {
         ScopedTimer tm(c, PT_TIMER_TAIL);
-        PT_HIP(c, launch_tail(cfg, c->scene, b, c->accel == PT_ACCEL_KD, c->traversal, split, levels, c->max_level, q[0], q[1],
+        PT_HIP(c, launch_tail(cfg, scene, b, c->accel == PT_ACCEL_KD, c->traversal, split, levels, c->max_level, q[0], q[1],
                               c->d_hit.ptr, c->d_sample_rad.ptr, c->d_qcount.ptr, c->d_block_stats.ptr));
     }
     {
@@ -640,7 +650,7 @@ void pt_destroy(PtContext* c) {
     c->d_nodes.release(); c->d_isect.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
     c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
     for (int k = 0; k < 2; k++) { c->q_ray_o[k].release(); c->q_ray_d[k].release(); c->q_beta[k].release(); }
-    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release(); c->d_keys.release();
+    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release(); c->d_keys.release(); c->d_eye.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

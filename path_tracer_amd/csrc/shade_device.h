@@ -231,7 +231,8 @@ __device__ __forceinline__ vec3 texel(const SceneGpu& sc, int tw, int th, int of
 //   SHADE_LAMBERTIAN  only Lambertian materials (textures, translucency and an environment allowed)
 //   SHADE_ALL         anything
 enum { SHADE_ALL = 0, SHADE_LAMBERTIAN = 1, SHADE_PLAIN = 2 };
-template <int KIND>
+// CAMERA: the queue holds camera rays, which carry no throughput record (see below).
+template <int KIND, bool CAMERA>
 __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& b, int level, int max_level, const QueueSet& in,
                                             const float4* __restrict__ hit, const QueueSet& out,
                                             float4* __restrict__ sample_rad, int n, int* s_out_ptr) {
@@ -251,7 +252,17 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
         int slot = 0;
 
         if (j < n) {
-            const float4 rd = in.ray_d[i], bt = in.beta[i], h = hit[i];
+            const float4 rd = in.ray_d[i], h = hit[i];
+            float4 bt;
+            if (!CAMERA) {
+                bt = in.beta[i];
+            } else {
+                // camera rays carry no throughput record: it is (1, 1, 1) and the sample slot follows from the
+                // position in the workgroup's region, the inverse of raygen_kernel's dealing
+                const int l = j >> 6;
+                const int slot0 = (l * b.blocks + (int)((blk + (long long)l * b.deal_shift) % b.blocks)) * 64 + (j & 63);
+                bt = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(slot0));
+            }
             const vec3 d = v3(rd.x, rd.y, rd.z);
             const vec3 beta = v3(bt.x, bt.y, bt.z);
             slot = __float_as_int(bt.w);

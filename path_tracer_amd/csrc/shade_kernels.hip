@@ -35,7 +35,10 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
     }
     if (threadIdx.x == 0) {
         qcount[blk] = written;
-        if (blk == 0) *b.overflow = 0;
+        if (blk == 0) {
+            *b.overflow = 0;
+            out.ray_o[0] = make_float4(eye.x, eye.y, eye.z, 1.0f);  // the one origin record of all camera rays
+        }
     }
     for (int j = threadIdx.x; j < written; j += blockDim.x) {
         const int l = j >> 6;
@@ -50,9 +53,9 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
         const float V = (py + (r2 * 2 - 1)) / float(cam.height) - 0.5f;
         const vec3 pix = eye + float(cam.aspect_film * U) * cu + float(cam.film * V) * cv - cam.dist * cw;
         const vec3 d = normalize_fast(pix - eye);
-        out.ray_o[region + j] = make_float4(eye.x, eye.y, eye.z, 1.0f);
+        // a camera ray is its direction: origin (the eye), miss scale (1), throughput (1, 1, 1) and sample slot
+        // (a function of the position in the region) are known to the stages that follow
         out.ray_d[region + j] = make_float4(d.x, d.y, d.z, __uint_as_float((1u << 8) | rng.dim));
-        out.beta[region + j] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(slot));
         sample_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
 }
@@ -65,7 +68,7 @@ __global__ void sample_keys_kernel(uint64_t seed, int sample0, int chunk, uint64
 }
 
 // ---- one bounce of shading for every path in the queue ----
-template <int KIND>
+template <int KIND, bool CAMERA>
 __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int level, int max_level, QueueSet in,
                                                     const float4* __restrict__ hit, QueueSet out,
                                                     float4* __restrict__ sample_rad, const int* __restrict__ qcount_in,
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
         if (threadIdx.x == 0) qcount_out[blk] = 0;
         return;
     }
-    const int produced = shade_region<KIND>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
+    const int produced = shade_region<KIND, CAMERA>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
     if (threadIdx.x == 0) qcount_out[blk] = produced;
 }
 
@@ -159,12 +162,13 @@ hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const Batch
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
                         int* qcount_out) {
-#define PT_SHADE(KIND)                                                                                                      \
-    hipLaunchKernelGGL(shade_kernel<KIND>, dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, in, hit, \
-                       out, sample_rad, qcount_in, qcount_out)
-    if (scene.shading_kind == SHADE_PLAIN) PT_SHADE(SHADE_PLAIN);
-    else if (scene.shading_kind == SHADE_LAMBERTIAN) PT_SHADE(SHADE_LAMBERTIAN);
-    else PT_SHADE(SHADE_ALL);
+#define PT_SHADE(KIND, CAMERA)                                                                                              \
+    hipLaunchKernelGGL((shade_kernel<KIND, CAMERA>), dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, \
+                       in, hit, out, sample_rad, qcount_in, qcount_out)
+    const bool camera = in.beta == nullptr;  // camera rays: directions only
+    if (scene.shading_kind == SHADE_PLAIN) { if (camera) PT_SHADE(SHADE_PLAIN, true); else PT_SHADE(SHADE_PLAIN, false); }
+    else if (scene.shading_kind == SHADE_LAMBERTIAN) { if (camera) PT_SHADE(SHADE_LAMBERTIAN, true); else PT_SHADE(SHADE_LAMBERTIAN, false); }
+    else { if (camera) PT_SHADE(SHADE_ALL, true); else PT_SHADE(SHADE_ALL, false); }
 #undef PT_SHADE
     return hipGetLastError();
 }

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int 
             const QueueSet& in = (level & 1) ? qb : qa;
             const QueueSet& out = (level & 1) ? qa : qb;
             trace_region<KD, false, SLAB, true, ALL_LDS>(sc, in.ray_o, in.ray_d, hit, n, region, block_stats, leave_k, lds);
-            n = shade_region<KIND>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
+            n = shade_region<KIND, false>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
             __syncthreads();  // s_out is rewritten by the next level's shading
         }
         if (threadIdx.x == 0) qcount[(size_t)(level + 1) * nb + blk] = n;  // the tally reads every level

@@ -303,7 +303,8 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
             if (cur == NO_RAY && j < n) {
                 slot = region + j;
-                const float4 ro = ray_o[slot], rd = ray_d[slot];
+                // camera rays share one origin record (the eye, miss scale 1) and are stored as directions only
+                const float4 ro = ray_o[sc.shared_origin ? 0 : slot], rd = ray_d[slot];
                 o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
                 miss_scale = ro.w;
                 best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
