@@ -65,7 +65,7 @@ struct SceneGpu {
     int n_records;    // intersection records in `isect`
     int n_refs;       // entries of `refs` (leaf_inline = 0)
     int shared_origin; // 1: every ray of the launch starts at ray_o[0] (camera rays are stored as directions only)
-    int shading_kind; // which instantiation of the shading code the scene needs (SHADE_ALL / _LAMBERTIAN / _PLAIN)
+    int shading_kind; // which instantiation of the shading code the scene needs (SHADE_ALL / _LAMBERTIAN / _PLAIN / _GLASS / _METAL)
     int planes_ok;  // every box coordinate is 0 or at least 1e-17 in magnitude (reciprocal slab form allowed)
 };
 

@@ -358,12 +358,15 @@ int flatten_and_upload(PtContext* c) {
     s.n_records = (int)(isect.size() / 4);
     s.n_refs = (int)refs.size();
     s.shared_origin = 0;
-    bool lambertian = true, plain = c->env.h == 0;
+    bool metal = false, glass = false, other = false, plain = c->env.h == 0;
     for (const HostMaterial& hm2 : m.materials) {
-        if (hm2.type != MAT_LAMBERTIAN) lambertian = false;
+        if (hm2.type == MAT_METAL) metal = true;
+        else if (hm2.type == MAT_GLASS) glass = true;
+        else if (hm2.type != MAT_LAMBERTIAN) other = true;
         if (hm2.textured || !(hm2.opacity >= 1.0f - PT_EPSILON)) plain = false;
     }
-    s.shading_kind = !lambertian ? 0 : (plain ? 2 : 1);  // SHADE_ALL / SHADE_PLAIN / SHADE_LAMBERTIAN of shade_device.h
+    // SHADE_ALL 0 / SHADE_LAMBERTIAN 1 / SHADE_PLAIN 2 / SHADE_GLASS 3 / SHADE_METAL 4 of shade_device.h
+    s.shading_kind = (other || (metal && glass)) ? 0 : (glass ? 3 : (metal ? 4 : (plain ? 2 : 1)));
     choose_lds_nodes(c);
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)

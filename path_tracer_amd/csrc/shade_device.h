@@ -229,8 +229,9 @@ __device__ __forceinline__ vec3 texel(const SceneGpu& sc, int tw, int th, int of
 // taken (and the registers they keep live) are compiled out:
 //   SHADE_PLAIN       only opaque, untextured Lambertian materials and no environment image
 //   SHADE_LAMBERTIAN  only Lambertian materials (textures, translucency and an environment allowed)
+//   SHADE_GLASS       Lambertian and glass materials;  SHADE_METAL  Lambertian and metal materials
 //   SHADE_ALL         anything
-enum { SHADE_ALL = 0, SHADE_LAMBERTIAN = 1, SHADE_PLAIN = 2 };
+enum { SHADE_ALL = 0, SHADE_LAMBERTIAN = 1, SHADE_PLAIN = 2, SHADE_GLASS = 3, SHADE_METAL = 4 };
 // CAMERA: the queue holds camera rays, which carry no throughput record (see below).
 template <int KIND, bool CAMERA>
 __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& b, int level, int max_level, const QueueSet& in,
@@ -348,7 +349,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                             b1 = beta * (1 - opacity);
                         }
                     }
-                } else if (KIND == SHADE_ALL && type == 1) {
+                } else if ((KIND == SHADE_ALL || KIND == SHADE_METAL) && type == 1) {
                     const float ra = rng.next();
                     const float rb = rng.next();
                     const vec3 hv = half_vector(N, view, rough, ra, rb);
@@ -363,7 +364,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                         d0 = light;
                         b0 = beta * (Kd * ln + Ks * spec);
                     }
-                } else if (KIND == SHADE_ALL && type == 2) {
+                } else if ((KIND == SHADE_ALL || KIND == SHADE_GLASS) && type == 2) {
                     const vec3 wi = d;
                     const float wn = dot(wi, N);
                     const float e1 = backface ? eta : PT_ETA_AIR, e2 = backface ? PT_ETA_AIR : eta;

@@ -168,6 +168,8 @@ hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const Batch
     const bool camera = in.beta == nullptr;  // camera rays: directions only
     if (scene.shading_kind == SHADE_PLAIN) { if (camera) PT_SHADE(SHADE_PLAIN, true); else PT_SHADE(SHADE_PLAIN, false); }
     else if (scene.shading_kind == SHADE_LAMBERTIAN) { if (camera) PT_SHADE(SHADE_LAMBERTIAN, true); else PT_SHADE(SHADE_LAMBERTIAN, false); }
+    else if (scene.shading_kind == SHADE_GLASS) { if (camera) PT_SHADE(SHADE_GLASS, true); else PT_SHADE(SHADE_GLASS, false); }
+    else if (scene.shading_kind == SHADE_METAL) { if (camera) PT_SHADE(SHADE_METAL, true); else PT_SHADE(SHADE_METAL, false); }
     else { if (camera) PT_SHADE(SHADE_ALL, true); else PT_SHADE(SHADE_ALL, false); }
 #undef PT_SHADE
     return hipGetLastError();

@@ -59,6 +59,8 @@ void launch_tail_variant(const LaunchCfg& cfg, const SceneGpu& scene, const Batc
     do {                                                                             \
         if (scene.shading_kind == SHADE_PLAIN) PT_TAIL(ALL, SHADE_PLAIN);            \
         else if (scene.shading_kind == SHADE_LAMBERTIAN) PT_TAIL(ALL, SHADE_LAMBERTIAN); \
+        else if (scene.shading_kind == SHADE_GLASS) PT_TAIL(ALL, SHADE_GLASS);       \
+        else if (scene.shading_kind == SHADE_METAL) PT_TAIL(ALL, SHADE_METAL);       \
         else PT_TAIL(ALL, SHADE_ALL);                                                \
     } while (0)
     if (fits_lds(scene)) PT_TAIL_KIND(true); else PT_TAIL_KIND(false);
