@@ -165,7 +165,8 @@ struct ScopedTimer {
     PtContext* c;
     TimedSpan span;
     bool on;
-    ScopedTimer(PtContext* ctx, int timer) : c(ctx), on(ctx->profile != 0) {
+    // profile 1: every stage; profile 2: the closest-hit kernel only (fewer events in the stream)
+    ScopedTimer(PtContext* ctx, int timer) : c(ctx), on(ctx->profile == 1 || (ctx->profile == 2 && timer == PT_TIMER_TRACE)) {
         if (!on) return;
         span.timer = timer;
         span.start = take_event(c);
@@ -683,7 +684,9 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             if (value > 62) return fail(c, PT_ERR_INVALID_ARG, "max level above 62");
             c->max_level = (int)value; break;
         case PT_OPT_COUNT_TESTS: c->count_tests = value != 0; break;
-        case PT_OPT_PROFILE: c->profile = value != 0; break;
+        case PT_OPT_PROFILE:
+            if (value > 2) return fail(c, PT_ERR_INVALID_ARG, "profile level above 2");
+            c->profile = (int)value; break;
         case PT_OPT_MAX_BATCH:
             if (value == 0 || value > ((uint64_t)1 << 28)) return fail(c, PT_ERR_INVALID_ARG, "batch size out of range");
             c->max_batch = (size_t)value; c->batch_alloc = 0; break;

@@ -9,5 +9,5 @@ for v in "$@"; do
   python3 -c "
 import json
 d=json.loads(open('$O/sw.json').read().strip().splitlines()[-1])
-print('$flag $v  Mrays/s %.0f  ms %.3f  %s  kd %s' % (d['value'], d['ms_per_step'], {k: round(x,3) for k,x in d['stage_ms_per_step'].items()}, round(d['kd_tree']['Mrays/s']) if 'kd_tree' in d else None))"
+print('$flag $v  Mrays/s %.0f  ms %.3f  %s  kd %s' % (d['value'], d['ms_per_step'], {k: round(x,3) for k,x in d['stage_ms_per_step'].items() if isinstance(x, float)}, round(d['kd_tree']['Mrays/s']) if 'kd_tree' in d else None))"
 done
