@@ -532,6 +532,7 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
 // stays the same, so a workgroup's region doubles relative to its samples with every halving.  A
 // flagged batch added nothing to the image (accumulate_kernel), so the pieces complete it exactly.
 int settle(PtContext* c) {
+    PT_HIP(c, hipSetDevice(c->device));  // the caller's thread may have another device current
     PT_HIP(c, hipStreamSynchronize(c->stream));
     drain_spans(c);
     bool repaired = false;
@@ -901,6 +902,7 @@ int pt_reset(PtContext* c) {
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
     const size_t n = (size_t)c->width * c->height * 3;
+    PT_HIP(c, hipSetDevice(c->device));
     c->issued.clear();  // whatever overflowed belongs to the image that is being thrown away
     PT_HIP(c, launch_clear(cfg_of(c), c->accum_ptr(), n));
     PT_HIP(c, launch_clear(cfg_of(c), c->d_frame.ptr, n));
@@ -925,6 +927,7 @@ int pt_resolve(PtContext* c) {
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
+    PT_HIP(c, hipSetDevice(c->device));
     ScopedTimer tm(c, PT_TIMER_ACCUM);
     PT_HIP(c, launch_resolve(cfg_of(c), c->accum_ptr(), c->d_frame.ptr, c->width * c->height, c->total_samples));
     return PT_OK;
