@@ -143,3 +143,40 @@ def test_full_size_frame_properties(gpu_device):
     o.render(spp=40, frames=1, threads=8)
     ref = o.image()
     assert abs(whole.mean() / 10.0 - ref.mean()) < 0.01 * ref.mean()
+
+
+def test_small_and_odd_shapes(gpu_device):
+    """Sizes and settings at the edges: one pixel, one sample, a prime-sized image, maxLevel 0 and 62, a
+    resolution change on a live context, a batch limit below one run of 64 samples, and a view that sees
+    nothing.  Every result must be finite, deterministic and independent of the batch limit."""
+    import path_tracer_amd as pta
+    s = load_gpu_scene("cornellbox.obj", orc.BVH)
+    for w, h, spp in ((1, 1, 1), (1, 1, 7), (3, 2, 1), (61, 37, 3), (64, 1, 2)):
+        s.set_resolution(w, h)
+        s.pathtrace(spp)
+        a = s.accumulation_buffer()
+        assert a.shape == (h, w, 3) and np.isfinite(a).all() and s.total_samples() == spp
+        t = load_gpu_scene("cornellbox.obj", orc.BVH)
+        t.set_option(pta.OPT_MAX_BATCH, 5)
+        t.set_resolution(w, h)
+        t.pathtrace(spp)
+        assert np.array_equal(t.accumulation_buffer(), a), (w, h, spp)
+        assert np.allclose(s.frame_buffer(), a / spp, rtol=1e-6)
+    for level in (0, 1, 62):
+        s.set_option(pta.OPT_MAX_LEVEL, level)
+        s.set_resolution(32, 24)
+        s.pathtrace(2)
+        img = s.accumulation_buffer()
+        assert np.isfinite(img).all()
+        if level == 0:
+            # only the light itself is visible: a hit at level 0 adds Ke, its bounce ends at level 1 > maxLevel
+            assert img.max() > 0 and (img == 0).mean() > 0.5
+    s.set_option(pta.OPT_MAX_LEVEL, 15)
+    # looking away from the scene: every camera ray misses, no environment -> black, and nothing is traced twice
+    s.set_camera(eye=(0, 0, 5), lookat=(0, 0, 10))
+    s.set_resolution(16, 16)
+    s.reset_counters()
+    s.pathtrace(4)
+    assert not s.accumulation_buffer().any()
+    c = s.counters()
+    assert c[pta.CNT_RAYS] == 16 * 16 * 4 and c[pta.CNT_HITS] == 0
