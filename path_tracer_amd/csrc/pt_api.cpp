@@ -492,10 +492,12 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     // the static refill is being measured: those are properties of the per-level kernels)
     // Russian roulette starts at level 5 (src/cs488.h:2153); a BVH walked in LDS is handed over one level later
     // (earlier is as fast, but keeps the per-level kernels measurable), a kd-tree walked in LDS after the camera
-    // rays (measured 9 % faster than at level 6), any other scene when its levels have thinned out further (the
+    // rays when the shading code is the light one (measured 9 % faster than at level 6; with the heavier shading
+    // instantiations the fused kernel's registers cost the walk more than that), any other scene when its levels have thinned out further (the
     // fused kernel keeps fewer waves resident, which shows where node fetches come from memory)
     const bool in_lds = c->scene.lds_nodes >= c->scene.n_nodes;
-    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD ? 1 : 6) : 8) : c->tail_level;
+    const bool light_shading = c->scene.shading_kind == 2;  // SHADE_PLAIN: the fused kernel keeps the walk's occupancy
+    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading ? 1 : 6) : 8) : c->tail_level;
     const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
     const int split = fuse ? tail : levels;
     for (int level = 0; level < split; level++) {
