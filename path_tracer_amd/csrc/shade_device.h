@@ -79,6 +79,12 @@ __device__ __forceinline__ Sampler make_sampler(uint64_t key, int pixel, uint32_
     return s;
 }
 
+// Position, within dealing round l, of the run that workgroup blk receives (see raygen_kernel).  The product
+// stays below the number of runs in a batch (at most 2^22), so 32-bit arithmetic is exact.
+__device__ __forceinline__ int dealt_position(int blk, int l, const BatchGpu& b) {
+    return (int)(((unsigned int)blk + (unsigned int)l * (unsigned int)b.deal_shift) % (unsigned int)b.blocks);
+}
+
 // slot -> (pixel, index of the sample within the batch's chunk)
 __device__ __forceinline__ void slot_to_sample(const BatchGpu& b, int slot, int& pixel, int& k) {
     const int pl = slot / b.chunk;
@@ -261,7 +267,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                 // camera rays carry no throughput record: it is (1, 1, 1) and the sample slot follows from the
                 // position in the workgroup's region, the inverse of raygen_kernel's dealing
                 const int l = j >> 6;
-                const int slot0 = (l * b.blocks + (int)((blk + (long long)l * b.deal_shift) % b.blocks)) * 64 + (j & 63);
+                const int slot0 = (l * b.blocks + dealt_position(blk, l, b)) * 64 + (j & 63);
                 bt = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(slot0));
             }
             const vec3 d = v3(rd.x, rd.y, rd.z);

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
     const int blk = blockIdx.x;
     const int runs = (b.n_slots + 63) / 64;  // runs in the batch; only the last one may be short
     const int full_rounds = runs / b.blocks, rest = runs % b.blocks;
-    const int my_runs = full_rounds + (((blk + (long long)full_rounds * b.deal_shift) % b.blocks) < rest ? 1 : 0);
+    const int my_runs = full_rounds + (dealt_position(blk, full_rounds, b) < rest ? 1 : 0);
     const size_t region = (size_t)blk * b.cap_block;
     const vec3 eye = v3(cam.eye[0], cam.eye[1], cam.eye[2]);
     const vec3 cu = v3(cam.u[0], cam.u[1], cam.u[2]), cv = v3(cam.v[0], cam.v[1], cam.v[2]), cw = v3(cam.w[0], cam.w[1], cam.w[2]);
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
         // the batch's short run, if there is one, is the last run of the last round, hence this
         // workgroup's last run
         const int l = my_runs - 1;
-        const int last_run = l * b.blocks + (int)((blk + (long long)l * b.deal_shift) % b.blocks);
+        const int last_run = l * b.blocks + dealt_position(blk, l, b);
         const int last_len = last_run == runs - 1 ? b.n_slots - last_run * 64 : 64;
         written = (my_runs - 1) * 64 + last_len;
     }
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
     }
     for (int j = threadIdx.x; j < written; j += blockDim.x) {
         const int l = j >> 6;
-        const int slot = (l * b.blocks + (int)((blk + (long long)l * b.deal_shift) % b.blocks)) * 64 + (j & 63);
+        const int slot = (l * b.blocks + dealt_position(blk, l, b)) * 64 + (j & 63);
         int pixel, k;
         slot_to_sample(b, slot, pixel, k);
         const int px = pixel % cam.width, py = pixel / cam.width;
