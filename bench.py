@@ -340,7 +340,8 @@ def main():
                 "workload": "%s %dx%d, %d spp/frame/GPU, SAH %s, progressive" % (
                     args.obj or WORKLOADS[args.workload][0] or "sponza stand-in (tools/make_sponza.py)", args.width, args.height,
                     args.spp, args.accel.upper()),
-                "parallelism": "sample-split x%d + RCCL reduce of the accumulation buffer" % world if world > 1 else "single GPU",
+                "parallelism": ("sample-split x%d + %s reduce of the accumulation buffer" % (
+                    world, "RCCL" if args.backend == "nccl" else "gloo (host-staged rehearsal)")) if world > 1 else "single GPU",
             },
             "spp_per_s": args.spp * world * args.steps / elapsed,
             "rays_per_sample": rays_local / (float(n_pix) * args.spp * args.steps),
