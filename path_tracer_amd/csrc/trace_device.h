@@ -178,7 +178,7 @@ __device__ __forceinline__ void node_step(const float4& q0, const float4& q1, co
 
 // The first LDS_STACK entries of a lane's traversal stack live in LDS (entry e of lane t at
 // [e * 256 + t]: consecutive lanes on consecutive banks), deeper ones in the lane's scratch array.
-enum { LDS_STACK_BVH = 12, LDS_STACK_KD = 8 };  // a kd-tree entry is two words (node, entry distance)
+enum { LDS_STACK_BVH = 16, LDS_STACK_KD = 8 };  // a kd-tree entry is two words (node, entry distance)
 template <bool KD> struct LdsStack { enum { ENTRIES = KD ? LDS_STACK_KD : LDS_STACK_BVH }; };
 // Triangles a lane tests per visit of the leaf phase.
 enum { LEAF_BURST = 4 };
