@@ -137,6 +137,8 @@ def make_scene(pta, args, device, accel):
         s.set_option(pta.OPT_TAIL_LEVEL, args.tail_level)
     if args.blocks_per_cu is not None:
         s.set_option(pta.OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    if args.streams is not None:
+        s.set_option(pta.OPT_STREAMS, args.streams)
     s.set_resolution(args.width, args.height)
     return s
 
@@ -211,6 +213,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None, help="samples per pixel per frame and per GPU")
     ap.add_argument("--lds-nodes", type=int, default=None, help="tree nodes staged in LDS by the trace kernel (PT_OPT_LDS_NODES)")
     ap.add_argument("--blocks-per-cu", type=int, default=None, help="PT_OPT_BLOCKS_PER_CU")
+    ap.add_argument("--streams", type=int, default=None, help="PT_OPT_STREAMS: batches (frames) in flight, 1..4")
     ap.add_argument("--tail-level", type=int, default=None, help="PT_OPT_TAIL_LEVEL (0 = one launch per level)")
     ap.add_argument("--traversal", type=lambda v: int(v, 0), default=None, help="PT_OPT_TRAVERSAL bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -288,15 +291,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # per-stage milliseconds from a few untimed frames with events around every kernel ...
+    # per-stage milliseconds from a few untimed frames with events around every kernel, one frame in
+    # flight at a time (with more, a kernel's span includes the time it shares the chip) ...
+    streams = scene.get_option(pta.OPT_STREAMS)
+    scene.set_option(pta.OPT_STREAMS, 1)
     scene.reset_counters()
     scene.set_option(pta.OPT_PROFILE, 1)
     stage_frames = min(args.steps, 5)
     for _ in range(stage_frames):
         step()
     fence()
-    stage_ms, _ = scene.timers()
+    stage_ms, stage_launches = scene.timers()
+    cs = scene.counters()
+    stage_rays_kernel = float(cs[pta.CNT_RAYS] - cs[pta.CNT_TAIL_RAYS])
+    stage_trace_launch_ms = stage_ms[pta.TIMER_TRACE] / max(stage_launches[pta.TIMER_TRACE], 1)
+    stage_trace_s = stage_ms[pta.TIMER_TRACE] * 1e-3
     stage_ms = [m / stage_frames for m in stage_ms]
+    scene.set_option(pta.OPT_PROFILE, 0)
+    scene.set_option(pta.OPT_STREAMS, streams)
     # ... and the timed region with events around the launches of the dominant kernel only
     scene.reset_counters()
     scene.set_option(pta.OPT_PROFILE, 2)
@@ -330,6 +342,7 @@ def main():
         trace_s = ms[pta.TIMER_TRACE] * 1e-3
         traffic, traffic_source = measured_traffic(args, world)
         achieved = rays_kernel * b_ray / trace_s * 1e-9 if trace_s > 0 else 0.0
+        achieved_alone = stage_rays_kernel * b_ray / stage_trace_s * 1e-9 if stage_trace_s > 0 else 0.0
         out = {
             "metric": "Mrays/s", "value": rays_total / elapsed * 1e-6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -340,6 +353,7 @@ def main():
                 "workload": "%s %dx%d, %d spp/frame/GPU, SAH %s, progressive" % (
                     args.obj or WORKLOADS[args.workload][0] or "sponza stand-in (tools/make_sponza.py)", args.width, args.height,
                     args.spp, args.accel.upper()),
+                "frames_in_flight": streams,
                 "parallelism": ("sample-split x%d + %s reduce of the accumulation buffer" % (
                     world, "RCCL" if args.backend == "nccl" else "gloo (host-staged rehearsal)")) if world > 1 else "single GPU",
             },
@@ -356,21 +370,27 @@ def main():
                 "rays_per_launch": rays_kernel / max(launches[pta.TIMER_TRACE], 1),
                 "rays_in_fused_tail_fraction": rays_tail / max(rays_local, 1.0),
                 "valu": measured_valu(args, world),
+                "note": ("%d frames are in flight on streams of their own in the timed region, so a launch's duration includes the time it "
+                         "shares the chip with the other frames' kernels; `alone` is the same kernel with one frame in flight "
+                         "(%d untimed frames)" % (streams, stage_frames)) if streams > 1 else None,
+                "alone": {"achieved": achieved_alone, "frac": achieved_alone / HBM_PEAK_GBS, "avg_launch_ms": stage_trace_launch_ms},
             },
             "stage_ms_per_step": {
-                "raygen": stage_ms[pta.TIMER_RAYGEN], "trace": ms[pta.TIMER_TRACE] / args.steps,
+                "raygen": stage_ms[pta.TIMER_RAYGEN], "trace": stage_ms[pta.TIMER_TRACE],
                 "shade": stage_ms[pta.TIMER_SHADE], "accumulate": stage_ms[pta.TIMER_ACCUM],
                 "fused_tail": stage_ms[pta.TIMER_TAIL],
-                "note": "trace: events in the timed region; the other stages: %d untimed frames with events on every kernel" % stage_frames,
+                "note": "%d untimed frames, one in flight at a time, events on every kernel (the timed region overlaps frames, so its stages do not add up to ms_per_step)" % stage_frames,
             },
             "max_queue": max_queue,
         }
 
     if world == 1 and rank == 0:
         if not args.no_kd and args.accel == "bvh":
+            scene.close()  # its streams go first: a process's streams share a few hardware queues
+            scene = None
             kd = make_scene(pta, args, local_rank, pta.KD)
             kd.set_stream(stream.cuda_stream)
-            for _ in range(2):
+            for _ in range(4):
                 kd.pathtrace(args.spp)
             kd.synchronize()
             kd.reset_counters()
@@ -391,7 +411,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    scene.close()
+    if scene is not None:
+        scene.close()
 
 
 if __name__ == "__main__":

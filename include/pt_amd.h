@@ -85,8 +85,14 @@ enum {
     PT_OPT_OBJ_EXTENDED = 11, /* 1: pt_load_obj also accepts what the reference's reader does not (src/cs488.h:1059 reads
                                  three vertices per face, :944-946 positive indices only): polygons as triangle fans,
                                  negative indices, face lines of any length.  Default 0 = the reference's behaviour */
-    PT_OPT_BLOCKS_PER_CU = 12 /* workgroups (queue regions) per compute unit a batch is split over, 1..8; 0 = chosen per
+    PT_OPT_BLOCKS_PER_CU = 12,/* workgroups (queue regions) per compute unit a batch is split over, 1..8; 0 = chosen per
                                  scene so that one launch of the trace kernel is resident at once */
+    PT_OPT_STREAMS = 13       /* batches in flight, 1..4 (default 2).  Consecutive batches (frames, when a frame is one
+                                 batch) run on internal streams with queues of their own, so the thinly populated late
+                                 levels of one overlap the early levels of the next; the kernels that touch the image
+                                 (accumulate, resolve, clear) stay on the context's stream in program order, so the image
+                                 and everything the caller orders on that stream are as with 1.  With PT_OPT_PROFILE the
+                                 per-kernel times then include the time a kernel shares the chip with another batch */
 };
 
 /* Counter indices for pt_get_counters (all cumulative since pt_reset_counters). */

@@ -58,7 +58,31 @@ struct IssuedBatch {
     int pixel0, n_pixels, sample0, chunk;
     int flag;  // index into the flag ring
 };
-enum { FLAG_RING = 1024 };
+enum { FLAG_RING = 1024, MAX_LANES = 4 };
+
+// Batches in flight: consecutive batches go to the lanes in turn, each lane with its own stream and
+// its own queues, so that the sparsely occupied late levels of one batch (and every kernel's
+// ramp-down) run beside the dense early levels of the next.  Only the kernels that touch the image
+// (accumulate, tally; resolve and clear anyway) run on the context's stream, in program order,
+// which keeps the image's summation order and everything a caller orders on that stream as with
+// one lane.
+struct Lane {
+    hipStream_t stream = nullptr;         // non-blocking; with one lane the context's stream is used instead
+    DeviceBuffer<float4> q_ray_o[2], q_ray_d[2], q_beta[2], d_hit, d_sample_rad;
+    DeviceBuffer<float4> d_eye;           // origin record shared by the camera rays of the lane's batch
+    DeviceBuffer<uint64_t> d_keys;        // sampler keys of the lane's batch
+    DeviceBuffer<int> d_qcount;
+    DeviceBuffer<unsigned long long> d_block_stats;
+    size_t batch_alloc = 0;
+    hipEvent_t done[2] = {nullptr, nullptr};      // the lane's kernels of a batch have been queued up to here
+    hipEvent_t consumed[2] = {nullptr, nullptr};  // the context's stream has read the batch's results
+    uint64_t uses = 0;
+    void release() {
+        for (int k = 0; k < 2; k++) { q_ray_o[k].release(); q_ray_d[k].release(); q_beta[k].release(); }
+        d_hit.release(); d_sample_rad.release(); d_eye.release(); d_keys.release(); d_qcount.release(); d_block_stats.release();
+        batch_alloc = 0;
+    }
+};
 
 struct PtContext {
     int device = 0;
@@ -106,15 +130,14 @@ struct PtContext {
     // film and queues
     DeviceBuffer<float> d_accum, d_frame;
     float* ext_accum = nullptr;
-    DeviceBuffer<float4> q_ray_o[2], q_ray_d[2], q_beta[2], d_hit, d_sample_rad;
-    DeviceBuffer<int> d_qcount;
-    DeviceBuffer<unsigned long long> d_totals, d_block_stats;
-    DeviceBuffer<float4> d_eye;           // origin record shared by the camera rays of the batch in flight
-    DeviceBuffer<uint64_t> d_keys;        // sampler keys of the batch in flight
+    Lane lanes[MAX_LANES];
+    int n_lanes = 2;                      // batches in flight (PT_OPT_STREAMS)
+    DeviceBuffer<unsigned long long> d_totals;
+    DeviceBuffer<unsigned long long> d_block_stats;  // of pt_trace_batch (the lanes have their own)
     DeviceBuffer<int> d_batch_flags;      // FLAG_RING overflow flags, one per batch in flight
     std::vector<IssuedBatch> issued;      // batches whose flags have not been looked at yet
     uint64_t batch_seq = 0, repaired_batches = 0;
-    size_t batch_alloc = 0;
+    size_t batch_hint = 0;                // samples of the largest batch of the frame being rendered
     uint64_t batch_rays = 0;  // rays traced through pt_trace_batch
 
     // measurement
@@ -166,16 +189,18 @@ struct ScopedTimer {
     TimedSpan span;
     bool on;
     // profile 1: every stage; profile 2: the closest-hit kernel only (fewer events in the stream)
-    ScopedTimer(PtContext* ctx, int timer) : c(ctx), on(ctx->profile == 1 || (ctx->profile == 2 && timer == PT_TIMER_TRACE)) {
+    hipStream_t stream;
+    ScopedTimer(PtContext* ctx, int timer, hipStream_t on_stream = nullptr)
+        : c(ctx), on(ctx->profile == 1 || (ctx->profile == 2 && timer == PT_TIMER_TRACE)), stream(on_stream ? on_stream : ctx->stream) {
         if (!on) return;
         span.timer = timer;
         span.start = take_event(c);
         span.stop = take_event(c);
-        (void)hipEventRecord(span.start, c->stream);
+        (void)hipEventRecord(span.start, stream);
     }
     ~ScopedTimer() {
         if (!on) return;
-        (void)hipEventRecord(span.stop, c->stream);
+        (void)hipEventRecord(span.stop, stream);
         c->spans.push_back(span);
     }
 };
@@ -419,74 +444,115 @@ void choose_lds_nodes(PtContext* c) {
     s.lds_nodes = best;
 }
 
-int ensure_queues(PtContext* c, size_t batch) {
-    if (batch <= c->batch_alloc) return PT_OK;
+// The lane's stream, events and per-workgroup statistics (first use) and queues for `batch` samples.
+int ensure_lane(PtContext* c, Lane& ln, size_t batch) {
+    if (c->n_lanes > 1 && !ln.stream) {
+        // non-blocking: the context's stream may be the null stream, which would otherwise order itself
+        // against every launch of the lane
+        // (a process's streams share a few hardware queues, GPU_MAX_HW_QUEUES; two busy streams that land
+        // on one queue run in order, which costs the overlap, never the result)
+        PT_HIP(c, hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            PT_HIP(c, hipEventCreateWithFlags(&ln.done[k], hipEventDisableTiming));
+            PT_HIP(c, hipEventCreateWithFlags(&ln.consumed[k], hipEventDisableTiming));
+        }
+    }
+    if (!ln.d_block_stats.ptr) {
+        PT_HIP(c, ln.d_block_stats.ensure((size_t)c->blocks * DC_BLOCK_COUNT));
+        // on the stream the lane's kernels run on: a lane's stream does not order itself against the null stream
+        PT_HIP(c, hipMemsetAsync(ln.d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long),
+                                 c->n_lanes > 1 ? ln.stream : c->stream));
+    }
+    if (batch <= ln.batch_alloc) return PT_OK;
     const size_t cap = batch * (size_t)c->queue_factor;
     for (int k = 0; k < 2; k++) {
-        PT_HIP(c, c->q_ray_o[k].ensure(cap));
-        PT_HIP(c, c->q_ray_d[k].ensure(cap));
-        PT_HIP(c, c->q_beta[k].ensure(cap));
+        PT_HIP(c, ln.q_ray_o[k].ensure(cap));
+        PT_HIP(c, ln.q_ray_d[k].ensure(cap));
+        PT_HIP(c, ln.q_beta[k].ensure(cap));
     }
-    PT_HIP(c, c->d_hit.ensure(cap));
-    PT_HIP(c, c->d_sample_rad.ensure(batch));
-    c->batch_alloc = batch;
+    PT_HIP(c, ln.d_hit.ensure(cap));
+    PT_HIP(c, ln.d_sample_rad.ensure(batch));
+    ln.batch_alloc = batch;
     return PT_OK;
 }
 
 // per-workgroup statistics summed on the host; the stream must be idle
 int read_block_stats(PtContext* c, unsigned long long out[DC_BLOCK_COUNT]) {
     std::vector<unsigned long long> h((size_t)c->blocks * DC_BLOCK_COUNT);
-    PT_HIP(c, hipMemcpy(h.data(), c->d_block_stats.ptr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int k = 0; k < DC_BLOCK_COUNT; k++) out[k] = 0;
-    for (int b = 0; b < c->blocks; b++)
-        for (int k = 0; k < DC_BLOCK_COUNT; k++) out[k] += h[(size_t)b * DC_BLOCK_COUNT + k];
+    for (int l = -1; l < MAX_LANES; l++) {
+        const unsigned long long* src = l < 0 ? c->d_block_stats.ptr : c->lanes[l].d_block_stats.ptr;
+        if (!src) continue;
+        PT_HIP(c, hipMemcpy(h.data(), src, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int b = 0; b < c->blocks; b++)
+            for (int k = 0; k < DC_BLOCK_COUNT; k++) out[k] += h[(size_t)b * DC_BLOCK_COUNT + k];
+    }
     return PT_OK;
 }
 
 int clear_block_stats(PtContext* c) {
-    PT_HIP(c, hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)));
+    for (int l = -1; l < MAX_LANES; l++) {
+        unsigned long long* dst = l < 0 ? c->d_block_stats.ptr : c->lanes[l].d_block_stats.ptr;
+        if (dst) PT_HIP(c, hipMemset(dst, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)));
+    }
+    PT_HIP(c, hipStreamSynchronize(nullptr));  // the lanes' streams do not wait for the null stream by themselves
     return PT_OK;
 }
 
-// One wavefront batch: camera rays, then trace + shade per bounce level, then accumulate.
+// One wavefront batch: camera rays, then trace + shade per bounce level on the batch's lane, then
+// accumulate on the context's stream.
 int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int sample0, int chunk) {
     BatchGpu b;
     b.pixel0 = pixel0; b.n_pixels = n_pixels; b.chunk = chunk; b.sample0 = sample0;
     b.seed = c->seed;
     b.n_slots = n_pixels * chunk;
+    Lane& ln = c->lanes[c->batch_seq % (uint64_t)c->n_lanes];
+    const bool own_stream = c->n_lanes > 1;
+    {
+        const size_t need = (size_t)b.n_slots > c->batch_hint ? (size_t)b.n_slots : c->batch_hint;
+        const int rc = ensure_lane(c, ln, need);
+        if (rc != PT_OK) return rc;
+    }
     // workgroups sharing the batch: about 2048 camera samples each, at most the resident grid
     int nb = (b.n_slots + 2047) / 2048;
     if (c->resident_per_cu <= 0) c->resident_per_cu = trace_resident_blocks_per_cu(c->scene, c->accel == PT_ACCEL_KD, c->traversal);
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : c->resident_per_cu;
+    // with another batch in flight beside this one, five regions per CU leave its kernels room (measured: 5 or 6
+    // instead of 8 gains 3-5 % on the cornellbox and the teapot, nothing elsewhere)
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (own_stream && c->resident_per_cu > 5 ? 5 : c->resident_per_cu);
     const int most = c->cus * per_cu;
     nb = nb < 1 ? 1 : (nb > most ? most : nb);
     b.blocks = nb;
     b.slots_block = (((b.n_slots + 63) / 64 + nb - 1) / nb) * 64;  // runs of 64 samples dealt in rounds
     b.deal_shift = nb > 2 ? ((int)(nb * 0.6180339887) | 1) : 0;
-    b.cap_block = (int)((c->batch_alloc * (size_t)c->queue_factor) / (size_t)nb);
+    b.cap_block = (int)((ln.batch_alloc * (size_t)c->queue_factor) / (size_t)nb);
     IssuedBatch rec;
     rec.cam = cam; rec.pixel0 = pixel0; rec.n_pixels = n_pixels; rec.sample0 = sample0; rec.chunk = chunk;
     rec.flag = (int)(c->batch_seq++ % FLAG_RING);
     b.overflow = c->d_batch_flags.ptr + rec.flag;
-    PT_HIP(c, c->d_keys.ensure((size_t)(chunk > 1024 ? chunk : 1024)));
-    PT_HIP(c, c->d_eye.ensure(1));
-    b.keys = c->d_keys.ptr;
-    const LaunchCfg cfg = cfg_of(c);
+    PT_HIP(c, ln.d_keys.ensure((size_t)(chunk > 1024 ? chunk : 1024)));
+    PT_HIP(c, ln.d_eye.ensure(1));
+    b.keys = ln.d_keys.ptr;
+    const LaunchCfg image_cfg = cfg_of(c);  // kernels that touch the image
+    LaunchCfg cfg = image_cfg;              // kernels of the batch proper
+    if (own_stream) cfg.stream = ln.stream;
+    const int turn = (int)(ln.uses++ & 1);
+    // the lane's previous batch must have been accumulated before its buffers are written again
+    if (own_stream && ln.uses > 1) PT_HIP(c, hipStreamWaitEvent(ln.stream, ln.consumed[turn ^ 1], 0));
     const int levels = c->max_level + 2;  // levels 0 .. maxLevel+1; the last one only resolves misses
     // every stage writes every workgroup's count of the next level, so the counts need no clearing
-    PT_HIP(c, c->d_qcount.ensure(((size_t)levels + 1) * (size_t)c->blocks));
+    PT_HIP(c, ln.d_qcount.ensure(((size_t)levels + 1) * (size_t)c->blocks));
     QueueSet q[2];
-    for (int k = 0; k < 2; k++) { q[k].ray_o = c->q_ray_o[k].ptr; q[k].ray_d = c->q_ray_d[k].ptr; q[k].beta = c->q_beta[k].ptr; }
+    for (int k = 0; k < 2; k++) { q[k].ray_o = ln.q_ray_o[k].ptr; q[k].ray_d = ln.q_ray_d[k].ptr; q[k].beta = ln.q_beta[k].ptr; }
     // camera rays are stored as directions only: one shared origin record, no throughputs
     QueueSet camera_rays = q[0];
-    camera_rays.ray_o = c->d_eye.ptr;
+    camera_rays.ray_o = ln.d_eye.ptr;
     camera_rays.beta = nullptr;
     const SceneGpu& scene = c->scene;
     SceneGpu scene0 = c->scene;
     scene0.shared_origin = 1;
     {
-        ScopedTimer tm(c, PT_TIMER_RAYGEN);
-        PT_HIP(c, launch_raygen(cfg, cam, b, camera_rays, c->d_sample_rad.ptr, c->d_qcount.ptr));
+        ScopedTimer tm(c, PT_TIMER_RAYGEN, cfg.stream);
+        PT_HIP(c, launch_raygen(cfg, cam, b, camera_rays, ln.d_sample_rad.ptr, ln.d_qcount.ptr));
     }
     // the deep, sparsely populated levels run in one fused launch (not while tests are counted or
     // the static refill is being measured: those are properties of the per-level kernels)
@@ -504,26 +570,31 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
         const QueueSet& in = level == 0 ? camera_rays : q[level & 1];
         const QueueSet& out = q[(level + 1) & 1];
         {
-            ScopedTimer tm(c, PT_TIMER_TRACE);
+            ScopedTimer tm(c, PT_TIMER_TRACE, cfg.stream);
             PT_HIP(c, launch_trace(cfg, level == 0 ? scene0 : scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, in.ray_o, in.ray_d,
-                                   c->d_hit.ptr, c->d_qcount.ptr + (size_t)level * nb, 0, nb, b.cap_block, c->d_block_stats.ptr));
+                                   ln.d_hit.ptr, ln.d_qcount.ptr + (size_t)level * nb, 0, nb, b.cap_block, ln.d_block_stats.ptr));
         }
         {
-            ScopedTimer tm(c, PT_TIMER_SHADE);
-            PT_HIP(c, launch_shade(cfg, scene, b, level, c->max_level, in, c->d_hit.ptr, out, c->d_sample_rad.ptr,
-                                   c->d_qcount.ptr + (size_t)level * nb, c->d_qcount.ptr + (size_t)(level + 1) * nb));
+            ScopedTimer tm(c, PT_TIMER_SHADE, cfg.stream);
+            PT_HIP(c, launch_shade(cfg, scene, b, level, c->max_level, in, ln.d_hit.ptr, out, ln.d_sample_rad.ptr,
+                                   ln.d_qcount.ptr + (size_t)level * nb, ln.d_qcount.ptr + (size_t)(level + 1) * nb));
         }
     }
     if (fuse) {
-        ScopedTimer tm(c, PT_TIMER_TAIL);
+        ScopedTimer tm(c, PT_TIMER_TAIL, cfg.stream);
         PT_HIP(c, launch_tail(cfg, scene, b, c->accel == PT_ACCEL_KD, c->traversal, split, levels, c->max_level, q[0], q[1],
-                              c->d_hit.ptr, c->d_sample_rad.ptr, c->d_qcount.ptr, c->d_block_stats.ptr));
+                              ln.d_hit.ptr, ln.d_sample_rad.ptr, ln.d_qcount.ptr, ln.d_block_stats.ptr));
+    }
+    if (own_stream) {
+        PT_HIP(c, hipEventRecord(ln.done[turn], ln.stream));
+        PT_HIP(c, hipStreamWaitEvent(c->stream, ln.done[turn], 0));
     }
     {
         ScopedTimer tm(c, PT_TIMER_ACCUM);
-        PT_HIP(c, launch_accumulate(cfg, b, c->d_sample_rad.ptr, c->accum_ptr(), c->d_totals.ptr));
-        PT_HIP(c, launch_tally(cfg, c->d_qcount.ptr, levels, nb, split, c->d_totals.ptr));
+        PT_HIP(c, launch_accumulate(image_cfg, b, ln.d_sample_rad.ptr, c->accum_ptr(), c->d_totals.ptr));
+        PT_HIP(c, launch_tally(image_cfg, ln.d_qcount.ptr, levels, nb, split, c->d_totals.ptr));
     }
+    if (own_stream) PT_HIP(c, hipEventRecord(ln.consumed[turn], c->stream));
     c->samples_started += (uint64_t)b.n_slots;
     c->issued.push_back(rec);
     return PT_OK;
@@ -595,8 +666,8 @@ int render_range(PtContext* c, int spp_frame, int first, int count) {
         size_t pix_per_batch = n_pixels;
         if (chunk == 0) { chunk = 1; pix_per_batch = c->max_batch; }
         if (chunk > (size_t)count) chunk = (size_t)count;
-        int rc = ensure_queues(c, pix_per_batch * chunk);
-        if (rc != PT_OK) return rc;
+        int rc = PT_OK;
+        c->batch_hint = pix_per_batch * chunk;  // every lane's queues are sized for the frame's largest batch
         for (size_t p0 = 0; p0 < n_pixels; p0 += pix_per_batch) {
             const size_t np = p0 + pix_per_batch <= n_pixels ? pix_per_batch : n_pixels - p0;
             for (int s = 0; s < count; s += (int)chunk) {
@@ -643,6 +714,7 @@ int pt_create(int device, PtContext** out) {
         pt_destroy(c);
         return PT_ERR_HIP;
     }
+    (void)hipStreamSynchronize(nullptr);  // the clears above, before any stream of the context is used
     *out = c;
     return PT_OK;
 }
@@ -656,8 +728,15 @@ void pt_destroy(PtContext* c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->d_nodes.release(); c->d_isect.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
     c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
-    for (int k = 0; k < 2; k++) { c->q_ray_o[k].release(); c->q_ray_d[k].release(); c->q_beta[k].release(); }
-    c->d_hit.release(); c->d_sample_rad.release(); c->d_qcount.release(); c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release(); c->d_keys.release(); c->d_eye.release();
+    for (Lane& ln : c->lanes) {
+        if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
+        for (int k = 0; k < 2; k++) {
+            if (ln.done[k]) (void)hipEventDestroy(ln.done[k]);
+            if (ln.consumed[k]) (void)hipEventDestroy(ln.consumed[k]);
+        }
+        ln.release();
+    }
+    c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -692,10 +771,10 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             c->profile = (int)value; break;
         case PT_OPT_MAX_BATCH:
             if (value == 0 || value > ((uint64_t)1 << 28)) return fail(c, PT_ERR_INVALID_ARG, "batch size out of range");
-            c->max_batch = (size_t)value; c->batch_alloc = 0; break;
+            c->max_batch = (size_t)value; c->batch_hint = 0; for (Lane& ln : c->lanes) ln.batch_alloc = 0; break;
         case PT_OPT_QUEUE_FACTOR:
             if (value < 2 || value > 64) return fail(c, PT_ERR_INVALID_ARG, "queue factor out of range");
-            c->queue_factor = (int)value; c->batch_alloc = 0; break;
+            c->queue_factor = (int)value; c->batch_hint = 0; for (Lane& ln : c->lanes) ln.batch_alloc = 0; break;
         case PT_OPT_LDS_NODES:
             if (value > 2048 && value != 65535) return fail(c, PT_ERR_INVALID_ARG, "at most 2048 nodes fit the LDS stage");
             c->lds_nodes_opt = value == 65535 ? -1 : (int)value;
@@ -709,6 +788,10 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
         case PT_OPT_BUILD_THREADS:
             if (value > 256) return fail(c, PT_ERR_INVALID_ARG, "more than 256 builder threads");
             c->build_threads = (int)value; break;
+        case PT_OPT_STREAMS:
+            if (value < 1 || value > MAX_LANES) return fail(c, PT_ERR_INVALID_ARG, "between 1 and 4 batches in flight");
+            if (c->device != PT_DEVICE_NONE && c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+            c->n_lanes = (int)value; break;
         case PT_OPT_TAIL_LEVEL:
             if (value > 64 && value != 255) return fail(c, PT_ERR_INVALID_ARG, "tail level above 64");
             c->tail_level = (int)value; break;
@@ -729,6 +812,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
         case PT_OPT_LDS_NODES: *value = c->built ? (uint64_t)c->scene.lds_nodes : (c->lds_nodes_opt < 0 ? 65535u : (uint64_t)c->lds_nodes_opt); break;
         case PT_OPT_TRAVERSAL: *value = (uint64_t)c->traversal; break;
         case PT_OPT_TAIL_LEVEL: *value = (uint64_t)c->tail_level; break;
+        case PT_OPT_STREAMS: *value = (uint64_t)c->n_lanes; break;
         case PT_OPT_BUILD_THREADS: *value = (uint64_t)c->build_threads; break;
         case PT_OPT_OBJ_EXTENDED: *value = (uint64_t)c->obj_extended; break;
         case PT_OPT_BLOCKS_PER_CU: *value = (uint64_t)c->blocks_per_cu; break;
@@ -856,6 +940,7 @@ int pt_build(PtContext* c, int accel) {
     if (accel == PT_ACCEL_KD) build_kd(c->mesh, c->tree, c->build_threads); else build_bvh(c->mesh, c->tree, c->build_threads);
     if (c->device == PT_DEVICE_NONE) return PT_OK;  // tree available through pt_get_tree; not renderable
     PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipStreamSynchronize(c->stream));  // no lane reads the old scene any more
     int rc = flatten_and_upload(c);
     if (rc != PT_OK) return rc;
     c->built = true;

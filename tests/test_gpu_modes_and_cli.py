@@ -227,6 +227,42 @@ def test_fused_tail_gives_the_per_level_image(gpu_device, obj, accel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("obj,accel", [("cornellbox.obj", pta.BVH), ("cornellbox.obj", pta.KD), ("teapot.obj", pta.BVH)])
+def test_frames_in_flight_do_not_change_the_image(gpu_device, obj, accel):
+    """PT_OPT_STREAMS: consecutive batches run on streams of their own, but the kernels that touch
+    the image stay on the context's stream in program order, so frames, counters and the image after
+    every frame are bit for bit those of one batch at a time -- also with many small batches per
+    frame, with a restart in between and with an external accumulation buffer."""
+    def render(lanes, max_batch):
+        s = load_gpu_scene(obj, accel, env="probe_64.hdr" if obj.startswith("teapot") else None)
+        s.set_option(pta.OPT_STREAMS, lanes)
+        assert s.get_option(pta.OPT_STREAMS) == lanes
+        s.set_option(pta.OPT_MAX_BATCH, max_batch)
+        s.set_resolution(96, 72)
+        s.pathtrace(3)
+        s.reset()                      # a restart with batches still in flight (src/cs488.h:2288-2290)
+        frames = []
+        for _ in range(5):
+            s.pathtrace(4)
+            frames.append(s.frame_buffer())
+        return frames, s.accumulation_buffer(), s.counters()
+
+    for max_batch in (1 << 24, 96 * 72, 1000):
+        ref_frames, ref_acc, ref_c = render(1, max_batch)
+        for lanes in (2, 3, 4):
+            frames, acc, c = render(lanes, max_batch)
+            assert np.array_equal(acc, ref_acc)
+            for a, b in zip(frames, ref_frames):
+                assert np.array_equal(a, b)
+            assert list(c[:9]) == list(ref_c[:9])
+    s = load_gpu_scene(obj, accel)
+    with pytest.raises(Exception):
+        s.set_option(pta.OPT_STREAMS, 5)
+    with pytest.raises(Exception):
+        s.set_option(pta.OPT_STREAMS, 0)
+
+
+@pytest.mark.gpu
 def test_cli_scripted_input(gpu_device, tmp_path):
     """Scripted events stand in for the window's callbacks (src/cs488.h:240-349): a translation keeps
     accumulating (the reference restarts only when view direction or right vector change, :2266-2293),
