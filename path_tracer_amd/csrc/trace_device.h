@@ -102,6 +102,57 @@ __device__ __forceinline__ void triangle_test(const float4& r0, const float4& r1
     }
 }
 
+// The same test for one round of the leaf phase, for all lanes of the wave at once: `valid` is false
+// for a lane that has no triangle in this round (it computes on a repeated record and its result is
+// dropped).  Which of the two quotient forms is used is decided per wave, not per lane (both give
+// RN(numerator / D) for operands inside the guard, and the division is right for all), and the
+// acceptance test of the guarded form is folded into a minimum and a maximum: everything in it is
+// finite there, so 0 <= alpha, beta, gamma, t  <=>  min(alpha, beta, gamma, t) >= 0, likewise <= 1,
+// and t <= FLT_MAX follows from t < best.t.  Few scalar instructions result, which is what the
+// leaf phase is short of.
+template <bool FAST_DIV>
+__device__ __forceinline__ void triangle_round(const float4& r0, const float4& r1, const float4& r2, const float4& r3,
+                                               vec3 o, vec3 d, bool valid, Best& best) {
+    const vec3 a = v3(r1.x, r1.y, r1.z);
+    const vec3 b = v3(r2.x, r2.y, r2.z);
+    const vec3 ab = v3(r3.x, r3.y, r3.z);
+    const vec3 e = v3(r0.x, r0.y, r0.z) - o;
+    const float D = dot(ab, d);
+    const float Da = dot(cross(e, b), d);
+    const float Db = dot(cross(a, e), d);
+    const float Dc = dot(ab, e);
+    const bool live = valid && D != 0;
+    bool guarded = false;
+    if (FAST_DIV) {
+        const float lo = fminf(fminf(fabsf(Da), fabsf(Db)), fabsf(Dc));
+        const float hi = fmaxf(fmaxf(fabsf(Da), fabsf(Db)), fabsf(Dc));
+        const bool in_guard = lo >= 1e-22f && hi <= 1e15f && fabsf(D) >= 1e-15f && fabsf(D) <= 1e15f;
+        guarded = !__any(live && !in_guard);
+    }
+    float beta, gamma, t;
+    bool accept;
+    if (guarded) {
+        const float r = exact_reciprocal(D);
+        beta = div_by_recip(Da, D, r);
+        gamma = div_by_recip(Db, D, r);
+        t = div_by_recip(Dc, D, r);
+        const float alpha = 1 - beta - gamma;
+        const float least = fminf(fminf(fminf(alpha, beta), gamma), t);
+        const float most = fmaxf(fmaxf(alpha, beta), gamma);
+        accept = live && least >= 0.0f && most <= 1.0f && t < best.t;
+    } else {
+        beta = Da / D;
+        gamma = Db / D;
+        t = Dc / D;
+        const float alpha = 1 - beta - gamma;
+        accept = live && 0 <= alpha && alpha <= 1 && 0 <= beta && beta <= 1 && 0 <= gamma && gamma <= 1 && 0.0f <= t && t <= FLT_MAX && t < best.t;
+    }
+    best.t = accept ? t : best.t;
+    best.beta = accept ? beta : best.beta;
+    best.gamma = accept ? gamma : best.gamma;
+    best.tri = accept ? __float_as_int(r0.w) : best.tri;
+}
+
 // ---- slab test without the division sequence ---------------------------------------------------
 // SLAB_DIVIDE: the division form above, always.
 // SLAB_RECIP:  every quotient (plane - origin) / direction is formed from the per-ray reciprocal
@@ -176,10 +227,49 @@ __device__ __forceinline__ void node_step(const float4& q0, const float4& q1, co
     st.deferred_t = left_first ? tr : tl;
 }
 
-// The first LDS_STACK entries of a lane's traversal stack live in LDS (entry e of lane t at
-// [e * 256 + t]: consecutive lanes on consecutive banks), deeper ones in the lane's scratch array.
-enum { LDS_STACK_BVH = 16, LDS_STACK_KD = 8 };  // a kd-tree entry is two words (node, entry distance)
-template <bool KD> struct LdsStack { enum { ENTRIES = KD ? LDS_STACK_KD : LDS_STACK_BVH }; };
+// The same decisions for a ray that passed recip_ok, written so that the compiler needs no scalar
+// mask arithmetic for them (a gfx950 SIMD issues one scalar instruction per four cycles against one
+// vector instruction per two, and the short-circuit form of the conditions above costs 25 scalar
+// instructions per step).  All six quotients per box are finite here, so
+//   hit  <=>  t1 <= t2  and not (t1 < 0 and t2 < 0)  <=>  max(t1, 0) <= t2,
+// and with e = t1 for a hit box, +inf otherwise (or for an empty kd leaf):
+//   enter left / right  <=>  e_l < best / e_r < best;   left first  <=>  e_l < e_r
+// (if only the left is entered, e_l < best <= e_r; if only the right, e_r < best <= e_l; with both,
+// nearer first and the right one on ties); descend <=> min(e_l, e_r) < best, push <=> max(..) < best,
+// and the pushed child's entry distance is that max.
+template <bool KD>
+__device__ __forceinline__ void node_step_recip(const float4& q0, const float4& q1, const float4& q2, const float4& q3,
+                                                vec3 o, vec3 d, vec3 r, float best_t, NodeStep& st) {
+    const float lx1 = div_by_recip(q0.x - o.x, d.x, r.x), ly1 = div_by_recip(q0.y - o.y, d.y, r.y), lz1 = div_by_recip(q0.z - o.z, d.z, r.z);
+    const float lx2 = div_by_recip(q0.w - o.x, d.x, r.x), ly2 = div_by_recip(q1.x - o.y, d.y, r.y), lz2 = div_by_recip(q1.y - o.z, d.z, r.z);
+    const float l1 = fmaxf(fmaxf(fminf(lx1, lx2), fminf(ly1, ly2)), fminf(lz1, lz2));
+    const float l2 = fminf(fminf(fmaxf(lx1, lx2), fmaxf(ly1, ly2)), fmaxf(lz1, lz2));
+    const float rx1 = div_by_recip(q1.z - o.x, d.x, r.x), ry1 = div_by_recip(q1.w - o.y, d.y, r.y), rz1 = div_by_recip(q2.x - o.z, d.z, r.z);
+    const float rx2 = div_by_recip(q2.y - o.x, d.x, r.x), ry2 = div_by_recip(q2.z - o.y, d.y, r.y), rz2 = div_by_recip(q2.w - o.z, d.z, r.z);
+    const float r1 = fmaxf(fmaxf(fminf(rx1, rx2), fminf(ry1, ry2)), fminf(rz1, rz2));
+    const float r2 = fminf(fminf(fmaxf(rx1, rx2), fmaxf(ry1, ry2)), fmaxf(rz1, rz2));
+    const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+    float el = fmaxf(l1, 0.0f) <= l2 ? l1 : INFINITY;
+    float er = fmaxf(r1, 0.0f) <= r2 ? r1 : INFINITY;
+    if (KD) {
+        el = left == EMPTY_LEAF ? INFINITY : el;
+        er = right == EMPTY_LEAF ? INFINITY : er;
+    }
+    const bool left_first = el < er;
+    st.next = left_first ? left : right;
+    st.deferred = left_first ? right : left;
+    st.deferred_t = fmaxf(el, er);
+    st.descend = fminf(el, er) < best_t;
+    st.push = st.deferred_t < best_t;
+}
+
+// A lane's traversal stack: LdsStack::ENTRIES entries in LDS (entry e of lane t at [e * 256 + t]:
+// consecutive lanes on consecutive banks), deeper ones in the lane's scratch array.  The LDS array
+// has one more row that is never read: a step stores its deferred child unconditionally, into the
+// row above the top (dead until a push makes it the top) or, from a lane whose LDS rows are full,
+// into that spare row.
+enum { LDS_STACK_ROWS_BVH = 16, LDS_STACK_ROWS_KD = 8 };  // a kd-tree entry is two words (node, entry distance)
+template <bool KD> struct LdsStack { enum { ROWS = KD ? LDS_STACK_ROWS_KD : LDS_STACK_ROWS_BVH, ENTRIES = ROWS - 1 }; };
 // Triangles a lane tests per visit of the leaf phase.
 enum { LEAF_BURST = 4 };
 
@@ -204,7 +294,7 @@ template <bool KD>
 struct TraceLds {
     float4* nodes;          // dynamic LDS: lds_nodes node records, then (ALL_LDS) the leaf records
     unsigned int* stat;     // 4: hits, slab tests, triangle tests, next ray of the region
-    int* stack;             // LdsStack<KD>::ENTRIES * 256
+    int* stack;             // LdsStack<KD>::ROWS * 256
     float* stack_t;         // the same number of entry distances (kd-tree only)
 };
 
@@ -264,30 +354,48 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     const int refill_min = DYNAMIC ? ((leave_k_and_refill >> 8) ? (leave_k_and_refill >> 8) : 16) : 64;
     const int leave_k = leave_k_and_refill & 0xff;
 
-    // Takes the next deferred child; when none is left the ray is finished and its record written.
-    auto pop_or_finish = [&]() {
-        while (sp > 0) {
-            sp--;
-            // the LDS read is unconditional (clamped) and the rare deep entry overrides it, which
-            // keeps the common case a plain LDS load instead of a load through a generic pointer
-            const int e = sp < LDS_STACK ? sp : LDS_STACK - 1;
-            int ref = s_stack[e * 256 + tid];
-            float t_ref = 0.0f;
-            if (KD) t_ref = s_stack_t[e * 256 + tid];
-            asm volatile("" : "+v"(ref), "+v"(t_ref));  // keeps the two loads from being merged into one generic load
-            if (__builtin_expect(sp >= LDS_STACK, 0)) {
-                ref = deep[sp - LDS_STACK];
-                if (KD) t_ref = deep_t[sp - LDS_STACK];
+    // For the lanes that `want` it: takes the next deferred child, or, when none is left, finishes
+    // the ray and writes its record.  Called by all lanes of a region of code, with few branches:
+    // the LDS row is read unconditionally (clamped), deep entries and skipped kd entries are rare
+    // and handled behind wave-wide tests.
+    auto pop_or_finish = [&](bool want) {
+        const int top = sp - 1;
+        const int row = top < 0 ? 0 : (top < LDS_STACK ? top : LDS_STACK - 1);
+        int ref = s_stack[row * 256 + tid];
+        float t_ref = 0.0f;
+        if (KD) t_ref = s_stack_t[row * 256 + tid];
+        if (__builtin_expect(__any(want && top >= LDS_STACK), 0)) {
+            if (want && top >= LDS_STACK) {
+                ref = deep[top - LDS_STACK];
+                if (KD) t_ref = deep_t[top - LDS_STACK];
             }
-            if (KD && !(t_ref < best.t)) continue;
-            cur = ref;
-            return;
         }
-        if (best.tri >= 0) n_hit++;
-        // a miss carries the ray's miss scale where a hit has beta, so the shading stage reads one
-        // record per path instead of the ray's origin as well
-        hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.tri >= 0 ? best.beta : miss_scale, best.gamma);
-        cur = NO_RAY;
+        bool popped = want && top >= 0;
+        sp = popped ? top : sp;
+        if (KD) {  // a deferred child that the best hit has overtaken since is skipped (src/cs488.h:1366, 1369)
+            bool again = popped && !(t_ref < best.t);
+            while (__any(again)) {
+                if (again) {
+                    if (sp > 0) {
+                        sp--;
+                        if (sp < LDS_STACK) { ref = s_stack[sp * 256 + tid]; t_ref = s_stack_t[sp * 256 + tid]; }
+                        else { ref = deep[sp - LDS_STACK]; t_ref = deep_t[sp - LDS_STACK]; }
+                        again = !(t_ref < best.t);
+                    } else {
+                        popped = false;
+                        again = false;
+                    }
+                }
+            }
+        }
+        const bool finished = want && !popped;
+        if (finished) {
+            if (best.tri >= 0) n_hit++;
+            // a miss carries the ray's miss scale where a hit has beta, so the shading stage reads one
+            // record per path instead of the ray's origin as well
+            hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.tri >= 0 ? best.beta : miss_scale, best.gamma);
+        }
+        cur = popped ? ref : (finished ? (int)NO_RAY : cur);
     };
 
     while (true) {
@@ -342,49 +450,62 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 }
                 if (COUNT) n_box += 2;
                 NodeStep st;
-                if (SLAB == SLAB_RECIP && fast_ok) node_step<true, KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                // one form for the whole wave: the division form is right for every ray
+                if (SLAB == SLAB_RECIP && __all(fast_ok)) node_step_recip<KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
                 else node_step<false, KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
-                if (st.push) {
-                    if (__builtin_expect(sp < LDS_STACK, 1)) {
-                        s_stack[sp * 256 + tid] = st.deferred;
-                        if (KD) s_stack_t[sp * 256 + tid] = st.deferred_t;
-                    } else {
+                // the deferred child goes to the row above the top whether or not it is pushed (that row
+                // is dead until it is), or to the spare row once the lane's LDS rows are full
+                const int row = sp < LDS_STACK ? sp : LDS_STACK;
+                s_stack[row * 256 + tid] = st.deferred;
+                if (KD) s_stack_t[row * 256 + tid] = st.deferred_t;
+                if (__builtin_expect(__any(st.push && sp >= LDS_STACK), 0)) {
+                    if (st.push && sp >= LDS_STACK) {
                         deep[sp - LDS_STACK] = st.deferred;
                         if (KD) deep_t[sp - LDS_STACK] = st.deferred_t;
                     }
-                    sp++;
                 }
-                if (st.descend) cur = st.next; else pop_or_finish();
+                sp += st.push ? 1 : 0;
+                pop_or_finish(!st.descend);
+                cur = st.descend ? st.next : cur;
                 leaf_k = 0;
             }
         }
 
         // ---- leaf phase: every lane on a leaf tests up to LEAF_BURST of its triangles, in stored
         // order (src/cs488.h:1677-1681, 1350-1354); a larger leaf is finished in the next round, so
-        // one big leaf does not hold the other lanes
+        // one big leaf does not hold the other lanes.  A lane whose leaf ends earlier repeats its
+        // last record with the result switched off, so the rounds need no per-lane control flow.
         if ((unsigned int)cur > (unsigned int)NO_RAY) {
             const int off = ~cur;
             if (KD && !sc.leaf_inline) {
-                if (leaf_k == 0) leaf_n = ALL_LDS ? lds_refs[off] : sc.refs[off];
-                const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
-                for (; leaf_k < stop; leaf_k++) {
-                    if (COUNT) n_tri++;
-                    const float4* rec = ALL_LDS ? lds_records + 4 * lds_refs[off + 1 + leaf_k]
-                                                : sc.isect + 4 * (size_t)sc.refs[off + 1 + leaf_k];
-                    triangle_test<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, best);
+                const int n_here = ALL_LDS ? lds_refs[off] : sc.refs[off];
+                leaf_n = leaf_k == 0 ? n_here : leaf_n;
+#pragma unroll
+                for (int j = 0; j < LEAF_BURST; j++) {
+                    const bool valid = leaf_k + j < leaf_n;
+                    if (j > 0 && !__any(valid)) break;
+                    const int k = valid ? leaf_k + j : leaf_n - 1;
+                    if (COUNT) n_tri += valid ? 1 : 0;
+                    const float4* rec = ALL_LDS ? lds_records + 4 * lds_refs[off + 1 + k]
+                                                : sc.isect + 4 * (size_t)sc.refs[off + 1 + k];
+                    triangle_round<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, valid, best);
                 }
             } else {
-                const float4* rec = ALL_LDS ? lds_records + 4 * (off + leaf_k) : sc.isect + 4 * (size_t)(off + leaf_k);
-                float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                if (leaf_k == 0) leaf_n = __float_as_int(r1.w);
-                const int stop = leaf_k + LEAF_BURST < leaf_n ? leaf_k + LEAF_BURST : leaf_n;
-                for (; leaf_k < stop; leaf_k++) {
-                    if (COUNT) n_tri++;
-                    triangle_test<SLAB == SLAB_RECIP>(r0, r1, r2, r3, o, d, best);
-                    if (leaf_k + 1 < stop) { rec += 4; r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
+#pragma unroll
+                for (int j = 0; j < LEAF_BURST; j++) {
+                    const bool valid = j == 0 || leaf_k + j < leaf_n;
+                    if (j > 0 && !__any(valid)) break;
+                    const int k = valid ? leaf_k + j : leaf_n - 1;
+                    const float4* rec = ALL_LDS ? lds_records + 4 * (off + k) : sc.isect + 4 * (size_t)(off + k);
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+                    if (j == 0) leaf_n = leaf_k == 0 ? __float_as_int(r1.w) : leaf_n;  // a leaf's first record carries its size
+                    if (COUNT) n_tri += valid ? 1 : 0;
+                    triangle_round<SLAB == SLAB_RECIP>(r0, r1, r2, r3, o, d, valid, best);
                 }
             }
-            if (leaf_k >= leaf_n) { pop_or_finish(); leaf_k = 0; }
+            leaf_k += LEAF_BURST;
+            pop_or_finish(leaf_k >= leaf_n);
+            leaf_k = leaf_k >= leaf_n ? 0 : leaf_k;
         }
     }
 
