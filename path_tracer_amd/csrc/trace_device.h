@@ -43,6 +43,10 @@ namespace pt {
 
 namespace trace_dev {
 
+// The wave's mask of a per-lane condition, read straight from the comparison's result (__ballot
+// takes an int and costs a select and a second comparison per use).
+__device__ __forceinline__ unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 
 __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float hix, float hiy, float hiz,
                                           vec3 o, vec3 d, float& t_entry) {
@@ -127,7 +131,7 @@ __device__ __forceinline__ void triangle_round(const float4& r0, const float4& r
         const float lo = fminf(fminf(fabsf(Da), fabsf(Db)), fabsf(Dc));
         const float hi = fmaxf(fmaxf(fabsf(Da), fabsf(Db)), fabsf(Dc));
         const bool in_guard = lo >= 1e-22f && hi <= 1e15f && fabsf(D) >= 1e-15f && fabsf(D) <= 1e15f;
-        guarded = !__any(live && !in_guard);
+        guarded = lane_mask(live && !in_guard) == 0ull;
     }
     float beta, gamma, t;
     bool accept;
@@ -360,11 +364,11 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     // and handled behind wave-wide tests.
     auto pop_or_finish = [&](bool want) {
         const int top = sp - 1;
-        const int row = top < 0 ? 0 : (top < LDS_STACK ? top : LDS_STACK - 1);
+        const int row = min(max(top, 0), LDS_STACK - 1);
         int ref = s_stack[row * 256 + tid];
         float t_ref = 0.0f;
         if (KD) t_ref = s_stack_t[row * 256 + tid];
-        if (__builtin_expect(__any(want && top >= LDS_STACK), 0)) {
+        if (__builtin_expect(lane_mask(want && top >= LDS_STACK) != 0ull, 0)) {
             if (want && top >= LDS_STACK) {
                 ref = deep[top - LDS_STACK];
                 if (KD) t_ref = deep_t[top - LDS_STACK];
@@ -374,7 +378,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         sp = popped ? top : sp;
         if (KD) {  // a deferred child that the best hit has overtaken since is skipped (src/cs488.h:1366, 1369)
             bool again = popped && !(t_ref < best.t);
-            while (__any(again)) {
+            while (lane_mask(again) != 0ull) {
                 if (again) {
                     if (sp > 0) {
                         sp--;
@@ -400,7 +404,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
 
     while (true) {
         // ---- idle lanes take the next rays of the region, once enough of them are idle ----
-        const unsigned long long idle = __ballot(cur == NO_RAY);
+        const unsigned long long idle = lane_mask(cur == NO_RAY);
         const int n_idle = __popcll(idle);
         if (n_idle == 64 && drained) break;
         if (!drained && n_idle >= refill_min) {
@@ -437,9 +441,9 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         // ---- node phase: lanes on interior nodes walk until too few of them are left ----
         // (leave when nobody walks, or when the walkers are fewer than 1/k of the lanes waiting at a leaf)
         while (true) {
-            const int walking = __popcll(__ballot(cur >= 0));
+            const int walking = __popcll(lane_mask(cur >= 0));
             if (walking == 0) break;
-            if (leave_k > 0 && walking * leave_k < __popcll(__ballot((unsigned int)cur > (unsigned int)NO_RAY))) break;
+            if (leave_k > 0 && walking * leave_k < __popcll(lane_mask((unsigned int)cur > (unsigned int)NO_RAY))) break;
             if (cur >= 0) {
                 float4 q0, q1, q2, q3;
                 if (ALL_LDS || cur < staged) {
@@ -451,14 +455,14 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 if (COUNT) n_box += 2;
                 NodeStep st;
                 // one form for the whole wave: the division form is right for every ray
-                if (SLAB == SLAB_RECIP && __all(fast_ok)) node_step_recip<KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                if (SLAB == SLAB_RECIP && lane_mask(!fast_ok) == 0ull) node_step_recip<KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
                 else node_step<false, KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
                 // the deferred child goes to the row above the top whether or not it is pushed (that row
                 // is dead until it is), or to the spare row once the lane's LDS rows are full
-                const int row = sp < LDS_STACK ? sp : LDS_STACK;
+                const int row = min(sp, LDS_STACK);
                 s_stack[row * 256 + tid] = st.deferred;
                 if (KD) s_stack_t[row * 256 + tid] = st.deferred_t;
-                if (__builtin_expect(__any(st.push && sp >= LDS_STACK), 0)) {
+                if (__builtin_expect(lane_mask(st.push && sp >= LDS_STACK) != 0ull, 0)) {
                     if (st.push && sp >= LDS_STACK) {
                         deep[sp - LDS_STACK] = st.deferred;
                         if (KD) deep_t[sp - LDS_STACK] = st.deferred_t;
@@ -483,7 +487,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
 #pragma unroll
                 for (int j = 0; j < LEAF_BURST; j++) {
                     const bool valid = leaf_k + j < leaf_n;
-                    if (j > 0 && !__any(valid)) break;
+                    if (j > 0 && lane_mask(valid) == 0ull) break;
                     const int k = valid ? leaf_k + j : leaf_n - 1;
                     if (COUNT) n_tri += valid ? 1 : 0;
                     const float4* rec = ALL_LDS ? lds_records + 4 * lds_refs[off + 1 + k]
@@ -494,7 +498,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
 #pragma unroll
                 for (int j = 0; j < LEAF_BURST; j++) {
                     const bool valid = j == 0 || leaf_k + j < leaf_n;
-                    if (j > 0 && !__any(valid)) break;
+                    if (j > 0 && lane_mask(valid) == 0ull) break;
                     const int k = valid ? leaf_k + j : leaf_n - 1;
                     const float4* rec = ALL_LDS ? lds_records + 4 * (off + k) : sc.isect + 4 * (size_t)(off + k);
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
