@@ -103,7 +103,7 @@ def measured_valu(args, world):
     k = json.load(open(path))["kernels"].get("trace_kernel")
     if not k:
         return None
-    return {"issue_busy": k.get("valu_issue_busy"), "lane_occupancy": k.get("valu_lane_occupancy"),
+    return {"issue_busy": k.get("valu_issue_busy"), "salu_issue_busy": k.get("salu_issue_busy"), "lane_occupancy": k.get("valu_lane_occupancy"),
             "wave_instructions_per_launch": k["per_launch"].get("SQ_INSTS_VALU"), "source": "profiles/r01_pmc_valu.json"}
 
 

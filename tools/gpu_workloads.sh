@@ -6,7 +6,7 @@ cd $R
 : > $O/workloads_$T.jsonl
 for w in cornellbox cornellbox-glass cornellbox-metal cornellbox-alpha cornellball-glass teapot sponza; do
   for a in bvh kd; do
-    timeout -k 10 300 python bench.py --workload $w --accel $a --steps 10 --warmup 2 --no-cpu-baseline --no-kd > $O/wl.json 2> $O/wl.err || { tail $O/wl.err; exit 1; }
+    timeout -k 10 300 python bench.py --workload $w --accel $a --steps 20 --warmup 3 --no-cpu-baseline --no-kd > $O/wl.json 2> $O/wl.err || { tail $O/wl.err; exit 1; }
     tail -1 $O/wl.json >> $O/workloads_$T.jsonl
     python3 -c "
 import json

@@ -2,10 +2,13 @@
 """VALU-side summary of the render kernels from rocprofv3 --pmc passes and a kernel trace of the same
 program.  usage: pmc_valu.py <pmc_dir> [<pmc_dir> ...] --trace <kernel_trace_dir> --out <json> [--note text]
 
-Per kernel and per launch: wave-level VALU instructions, lane occupancy of those instructions
-(SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)), and the share of the chip's VALU issue slots the kernel
-used: a wave64 instruction occupies one of the 1024 SIMDs for 4 cycles (SQ_ACTIVE_INST_VALU counts
-those quad-cycles), so busy = 4 x SQ_ACTIVE_INST_VALU / (launch seconds x clock x 1024).
+Per kernel and per launch: wave-level VALU and SALU instructions, lane occupancy of the VALU
+instructions (SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)), and the share of a SIMD's issue capacity
+the kernel used for each kind.  The capacities are measured (tools/issue_rate_probe.hip, eight waves per
+SIMD, nominal 2.4 GHz): one wave64 VALU instruction per 2.41 cycles and one SALU instruction per 4.34
+cycles per SIMD; a mix costs about the larger of the two plus a tenth.  (SQ_ACTIVE_INST_VALU equals the
+instruction count, so it says nothing about how long an instruction holds the SIMD.)
+busy = instructions x cycles each / (launch seconds x clock x 1024 SIMDs).
 """
 import argparse
 import csv
@@ -16,6 +19,8 @@ from collections import defaultdict
 
 CLOCK_HZ = 2.4e9
 SIMDS = 256 * 4
+VALU_CYCLES = 2.41
+SALU_CYCLES = 4.34
 
 
 def short(k):
@@ -49,15 +54,18 @@ for f in glob.glob(os.path.join(a.trace, "**", "*kernel_trace.csv"), recursive=T
             dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
             nl[k] += 1
 
-out = {"note": a.note, "clock_hz": CLOCK_HZ, "simds": SIMDS, "kernels": {}}
+out = {"note": a.note, "clock_hz": CLOCK_HZ, "simds": SIMDS, "valu_cycles_per_instruction": VALU_CYCLES,
+       "salu_cycles_per_instruction": SALU_CYCLES, "kernels": {}}
 for k in sorted(tot):
     per = {c: tot[k][c] / max(len(disp[k][c]), 1) for c in tot[k]}
     sec = dur[k] / max(nl[k], 1)
     e = {"launches_profiled": max(len(v) for v in disp[k].values()), "avg_launch_s": sec, "per_launch": per}
     if "SQ_INSTS_VALU" in per and "SQ_THREAD_CYCLES_VALU" in per and per["SQ_INSTS_VALU"] > 0:
         e["valu_lane_occupancy"] = per["SQ_THREAD_CYCLES_VALU"] / (64.0 * per["SQ_INSTS_VALU"])
-    if "SQ_ACTIVE_INST_VALU" in per and sec > 0:
-        e["valu_issue_busy"] = 4.0 * per["SQ_ACTIVE_INST_VALU"] / (sec * CLOCK_HZ * SIMDS)
+    if "SQ_INSTS_VALU" in per and sec > 0:
+        e["valu_issue_busy"] = VALU_CYCLES * per["SQ_INSTS_VALU"] / (sec * CLOCK_HZ * SIMDS)
+    if "SQ_INSTS_SALU" in per and sec > 0:
+        e["salu_issue_busy"] = SALU_CYCLES * per["SQ_INSTS_SALU"] / (sec * CLOCK_HZ * SIMDS)
     if "SQ_INSTS_VALU_FLOPS_FP32" in per and sec > 0:
         e["fp32_tflops"] = per["SQ_INSTS_VALU_FLOPS_FP32"] / sec * 1e-12
     out["kernels"][k] = e
