@@ -204,6 +204,15 @@ int pt_use_external_accum(PtContext* ctx, void* device_ptr);
 int pt_save_png(PtContext* ctx, int which, const char* path);
 /* Raw float dump of the same image as a little-endian PFM file (bottom row first). */
 int pt_save_pfm(PtContext* ctx, int which, const char* path);
+/* Recording (the window's `F` key, src/cs488.h:255-266: GifBegin / GifEnd; :2297-2310: one GifWriteFrame per
+ * frame after Pathtrace, rows top-down, the same clamp-and-truncate as Image::save): pt_record_begin opens an
+ * animated GIF of the context's resolution (delay in 1/100 s; the reference uses 1), pt_record_frame appends the
+ * current frame buffer, pt_record_end closes the file (also done by pt_destroy). */
+int pt_record_begin(PtContext* ctx, const char* path, int delay_cs);
+int pt_record_frame(PtContext* ctx);
+int pt_record_end(PtContext* ctx);
+/* The same encoder on caller-supplied frames (n_frames x height x width x 3 bytes, rows top-down); needs no GPU. */
+int pt_encode_gif(const char* path, const uint8_t* rgb8, int n_frames, int width, int height, int delay_cs);
 
 /* ---- parity entry: Scene::intersect on a batch of rays (src/cs488.h:1750-1777) ------------- */
 /* rays6: n x (origin xyz, direction xyz) in host memory.  tri: index of the winning triangle in

@@ -36,7 +36,7 @@ EXPORTS = [
     "pt_get_env", "pt_build", "pt_get_tree", "pt_set_camera", "pt_set_resolution", "pt_reset", "pt_render",
     "pt_render_split", "pt_resolve", "pt_total_samples", "pt_synchronize", "pt_download", "pt_accum_device_ptr",
     "pt_use_external_accum", "pt_save_png", "pt_save_pfm", "pt_trace_batch", "pt_camera_rays", "pt_get_counters",
-    "pt_reset_counters", "pt_get_timers",
+    "pt_reset_counters", "pt_get_timers", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
 ]
 
 
@@ -84,6 +84,18 @@ def lib():
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def encode_gif(path, frames, delay_cs=1):
+    """Animated GIF from 8-bit RGB frames (n x height x width x 3, rows top-down) with the encoder of
+    the recording entries; needs no GPU."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    if frames.ndim != 4 or frames.shape[3] != 3:
+        raise ValueError("frames must be n x height x width x 3")
+    n, h, w, _ = frames.shape
+    rc = lib().pt_encode_gif(os.fsencode(path), frames.ctypes.data_as(C.POINTER(C.c_uint8)), n, w, h, int(delay_cs))
+    if rc != 0:
+        raise PtError(rc, "pt_encode_gif failed for %s" % path)
 
 
 def _ip(a):
@@ -274,6 +286,16 @@ class Scene:
 
     def save_pfm(self, path, which=1):
         self._check(self.L.pt_save_pfm(self.h, which, os.fsencode(path)))
+
+    # ---- recording (the window's F key, src/cs488.h:255-266, 2297-2310) ----
+    def record_begin(self, path, delay_cs=1):
+        self._check(self.L.pt_record_begin(self.h, os.fsencode(path), int(delay_cs)))
+
+    def record_frame(self):
+        self._check(self.L.pt_record_frame(self.h))
+
+    def record_end(self):
+        self._check(self.L.pt_record_end(self.h))
 
     # ---- parity entry ----
     def intersect(self, rays):

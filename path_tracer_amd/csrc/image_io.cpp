@@ -7,6 +7,7 @@
 #include <zlib.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 
 #include "scene.h"
@@ -255,6 +256,138 @@ void quantise_image(const float* rgb_bottom_up, int w, int h, std::vector<uint8_
             }
         }
     }
+}
+
+// ---- animated GIF out (the `F` recording of the reference's window, src/cs488.h:255-266, 2297-2310) ----
+// GIF89a, one global palette of 6 x 7 x 6 colour levels with a 4 x 4 ordered dither, every frame the
+// whole image, LZW with the usual variable code width.  (The reference hands its frames to gif.h,
+// which builds a palette per frame; only the container and the frame content are kept here.)
+namespace {
+
+const int GIF_R = 6, GIF_G = 7, GIF_B = 6;
+
+void put_le16(std::vector<uint8_t>& v, int x) { v.push_back((uint8_t)(x & 255)); v.push_back((uint8_t)((x >> 8) & 255)); }
+
+struct BitWriter {
+    std::vector<uint8_t>& out;
+    uint8_t block[255];
+    int fill = 0;
+    uint32_t acc = 0;
+    int bits = 0;
+    explicit BitWriter(std::vector<uint8_t>& o) : out(o) {}
+    void byte(uint8_t b) {
+        block[fill++] = b;
+        if (fill == 255) flush_block();
+    }
+    void flush_block() {
+        if (!fill) return;
+        out.push_back((uint8_t)fill);
+        out.insert(out.end(), block, block + fill);
+        fill = 0;
+    }
+    void code(uint32_t c, int width) {
+        acc |= c << bits;
+        bits += width;
+        while (bits >= 8) { byte((uint8_t)(acc & 255)); acc >>= 8; bits -= 8; }
+    }
+    void finish() {
+        if (bits > 0) byte((uint8_t)(acc & 255));
+        acc = 0; bits = 0;
+        flush_block();
+    }
+};
+
+// one image's indices -> LZW sub-blocks (minimum code size 8)
+void gif_lzw(const std::vector<uint8_t>& idx, std::vector<uint8_t>& out) {
+    const int min_size = 8, clear = 1 << min_size, eoi = clear + 1;
+    std::vector<uint16_t> next((size_t)4096 * 256, 0);  // next[code * 256 + byte] = longer string's code, 0 = none
+    BitWriter bw(out);
+    out.push_back((uint8_t)min_size);
+    int width = min_size + 1, last = eoi;
+    bw.code((uint32_t)clear, width);
+    int cur = -1;
+    for (uint8_t px : idx) {
+        if (cur < 0) { cur = px; continue; }
+        const uint16_t longer = next[(size_t)cur * 256 + px];
+        if (longer) { cur = longer; continue; }
+        bw.code((uint32_t)cur, width);
+        next[(size_t)cur * 256 + px] = (uint16_t)++last;
+        if (last >= (1 << width)) width++;
+        if (last == 4095) {  // table full: start over
+            bw.code((uint32_t)clear, width);
+            std::fill(next.begin(), next.end(), (uint16_t)0);
+            width = min_size + 1;
+            last = eoi;
+        }
+        cur = px;
+    }
+    if (cur >= 0) bw.code((uint32_t)cur, width);
+    bw.code((uint32_t)clear, width);
+    bw.code((uint32_t)eoi, min_size + 1);
+    bw.finish();
+    out.push_back(0);  // block terminator
+}
+
+}  // namespace
+
+bool GifWriter::begin(const char* path, int w, int h, int delay_cs, std::string& err) {
+    end();
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) { err = "image size does not fit a GIF"; return false; }
+    fp_ = fopen(path, "wb");
+    if (!fp_) { err = std::string("cannot write ") + path; return false; }
+    w_ = w; h_ = h; delay_ = delay_cs;
+    std::vector<uint8_t> hd;
+    const char sig[] = "GIF89a";
+    hd.insert(hd.end(), sig, sig + 6);
+    put_le16(hd, w); put_le16(hd, h);
+    hd.push_back(0xF7); hd.push_back(0); hd.push_back(0);  // global table of 256 entries, 8 bits per channel
+    for (int i = 0; i < 256; i++) {
+        const int r = i / (GIF_G * GIF_B), g = (i / GIF_B) % GIF_G, b = i % GIF_B;
+        const bool used = i < GIF_R * GIF_G * GIF_B;
+        hd.push_back(used ? (uint8_t)(r * 255 / (GIF_R - 1)) : 0);
+        hd.push_back(used ? (uint8_t)(g * 255 / (GIF_G - 1)) : 0);
+        hd.push_back(used ? (uint8_t)(b * 255 / (GIF_B - 1)) : 0);
+    }
+    const uint8_t loop[] = {0x21, 0xFF, 0x0B, 'N', 'E', 'T', 'S', 'C', 'A', 'P', 'E', '2', '.', '0', 3, 1, 0, 0, 0};
+    hd.insert(hd.end(), loop, loop + sizeof(loop));
+    if (fwrite(hd.data(), 1, hd.size(), fp_) != hd.size()) { err = "short write"; end(); return false; }
+    return true;
+}
+
+bool GifWriter::frame(const uint8_t* rgb_top_down, std::string& err) {
+    if (!fp_) { err = "no GIF is open"; return false; }
+    static const int bayer[16] = {0, 8, 2, 10, 12, 4, 14, 6, 3, 11, 1, 9, 15, 7, 13, 5};
+    std::vector<uint8_t> idx((size_t)w_ * h_);
+    for (int y = 0; y < h_; y++) {
+        for (int x = 0; x < w_; x++) {
+            const uint8_t* p = rgb_top_down + ((size_t)y * w_ + x) * 3;
+            const int t = bayer[(y & 3) * 4 + (x & 3)];  // 0..15: threshold of the ordered dither
+            auto level = [&](int v, int n) {
+                const int scaled = v * (n - 1) * 16 / 255;  // level in sixteenths
+                int q = scaled / 16 + ((scaled % 16) > t ? 1 : 0);
+                return q > n - 1 ? n - 1 : q;
+            };
+            idx[(size_t)y * w_ + x] = (uint8_t)((level(p[0], GIF_R) * GIF_G + level(p[1], GIF_G)) * GIF_B + level(p[2], GIF_B));
+        }
+    }
+    std::vector<uint8_t> out;
+    const uint8_t gce[] = {0x21, 0xF9, 4, 0x04, (uint8_t)(delay_ & 255), (uint8_t)((delay_ >> 8) & 255), 0, 0};
+    out.insert(out.end(), gce, gce + sizeof(gce));
+    out.push_back(0x2C);
+    put_le16(out, 0); put_le16(out, 0); put_le16(out, w_); put_le16(out, h_);
+    out.push_back(0);
+    gif_lzw(idx, out);
+    if (fwrite(out.data(), 1, out.size(), fp_) != out.size()) { err = "short write"; return false; }
+    frames_++;
+    return true;
+}
+
+void GifWriter::end() {
+    if (!fp_) return;
+    fputc(0x3B, fp_);
+    fclose(fp_);
+    fp_ = nullptr;
+    frames_ = 0;
 }
 
 }  // namespace pt

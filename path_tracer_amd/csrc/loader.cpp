@@ -94,7 +94,7 @@ void read_mtl(const std::string& path, const std::string& dir, std::vector<HostM
             cur.textured = true;
             cur.tex_path = dir + name;
             std::string err;
-            if (!load_png_rgb8(cur.tex_path.c_str(), cur.tex, cur.tex_w, cur.tex_h, err)) {
+            if (!load_texture_rgb8(cur.tex_path.c_str(), cur.tex, cur.tex_w, cur.tex_h, err)) {
                 fprintf(stderr, "Unable to load texture: %s\n", cur.tex_path.c_str());  // src/cs488.h:843
                 cur.tex.clear();
                 cur.tex_w = cur.tex_h = 0;

@@ -23,8 +23,8 @@
 // reference polls events, i.e. before the frame with that index is rendered (src/cs488.h:2283):
 //   <frame> key W|S|A|D|Q|Z      move eye and lookat by SCLFACT along view / right / up (src/cs488.h:270-298)
 //   <frame> key I                save the frame buffer as output<n>.png, n = int(1000 rand()) (:249-253)
-//   <frame> key F                start / stop recording (:255-268); recorded frames go to
-//                                output<n>_%04d.png instead of an animated .gif
+//   <frame> key F                start / stop recording (:255-268) into the animated output<n>.gif, one
+//                                frame per rendered frame (:2297-2310)
 //   <frame> key ESCAPE           leave the loop (:245-247)
 //   <frame> drag <dx> <dy>       cursor movement in pixels with the left button held (:317-344)
 //   <frame> save <file>          write the frame buffer (.png or .pfm)
@@ -231,8 +231,6 @@ int main(int argc, const char* argv[]) {
     F3 prev_view = view, prev_right = right;
     Pcg32 names;
     bool recording = false, quit = false;
-    std::string recording_prefix;
-    int recorded = 0;
     double total_seconds = 0.0;
     int frames_done = 0;
     for (int frame = 0; frame < opt.frames && !quit; frame++) {
@@ -255,13 +253,13 @@ int main(int argc, const char* argv[]) {
                 } else if (k == "F") {
                     if (!recording) {
                         char name[64];
-                        snprintf(name, sizeof(name), "output%d", int(1000.0 * names.rand()));
-                        recording_prefix = name;
-                        printf("Saving \"%s_%%04d.png\"...\n", name);
+                        snprintf(name, sizeof(name), "output%d.gif", int(1000.0 * names.rand()));  // src/cs488.h:258
+                        printf("Saving \"%s\"...\n", name);
+                        if ((rc = pt_record_begin(ctx, name, 1)) != PT_OK) return die(ctx, "opening the recording", rc);
                         recording = true;
-                        recorded = 0;
                         printf("(Recording started)\n");
                     } else {
+                        pt_record_end(ctx);
                         recording = false;
                         printf("(Recording done)\n");
                     }
@@ -297,10 +295,7 @@ int main(int argc, const char* argv[]) {
         std::cout << pt_total_samples(ctx) << std::endl;  // src/cs488.h:1896
         if (recording || !opt.sequence.empty()) {
             char name[1200];
-            if (recording) {
-                snprintf(name, sizeof(name), "%s_%04d.png", recording_prefix.c_str(), recorded++);
-                if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(ctx, "saving a recorded frame", rc);
-            }
+            if (recording && (rc = pt_record_frame(ctx)) != PT_OK) return die(ctx, "saving a recorded frame", rc);
             if (!opt.sequence.empty()) {
                 snprintf(name, sizeof(name), "%s%04d.png", opt.sequence.c_str(), frame);
                 if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(ctx, "saving a sequence frame", rc);

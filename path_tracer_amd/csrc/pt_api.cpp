@@ -140,6 +140,8 @@ struct PtContext {
     size_t batch_hint = 0;                // samples of the largest batch of the frame being rendered
     uint64_t batch_rays = 0;  // rays traced through pt_trace_batch
 
+    GifWriter recording;
+
     // measurement
     uint64_t samples_started = 0;
     std::vector<TimedSpan> spans;
@@ -1066,6 +1068,47 @@ static int save_image(PtContext* c, int which, const char* path, bool png) {
 
 int pt_save_png(PtContext* c, int which, const char* path) { return save_image(c, which, path, true); }
 int pt_save_pfm(PtContext* c, int which, const char* path) { return save_image(c, which, path, false); }
+
+// ---- recording ----
+int pt_record_begin(PtContext* c, const char* path, int delay_cs) {
+    if (!c || !path || delay_cs < 0 || delay_cs > 65535) return PT_ERR_INVALID_ARG;
+    if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
+    std::string err;
+    if (!c->recording.begin(path, c->width, c->height, delay_cs, err)) return fail(c, PT_ERR_IO, err);
+    return PT_OK;
+}
+
+int pt_record_frame(PtContext* c) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (!c->recording.open()) return fail(c, PT_ERR_NOT_READY, "pt_record_begin has not been called");
+    if (c->recording.width() != c->width || c->recording.height() != c->height)
+        return fail(c, PT_ERR_INVALID_ARG, "the resolution changed since pt_record_begin");
+    std::vector<float> img((size_t)c->width * c->height * 3);
+    int rc = pt_download(c, 1, img.data());
+    if (rc != PT_OK) return rc;
+    std::vector<uint8_t> q;
+    quantise_image(img.data(), c->width, c->height, q);
+    std::string err;
+    if (!c->recording.frame(q.data(), err)) return fail(c, PT_ERR_IO, err);
+    return PT_OK;
+}
+
+int pt_record_end(PtContext* c) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    c->recording.end();
+    return PT_OK;
+}
+
+int pt_encode_gif(const char* path, const uint8_t* rgb8, int n_frames, int width, int height, int delay_cs) {
+    if (!path || !rgb8 || n_frames < 0 || delay_cs < 0 || delay_cs > 65535) return PT_ERR_INVALID_ARG;
+    GifWriter g;
+    std::string err;
+    if (!g.begin(path, width, height, delay_cs, err)) return PT_ERR_IO;
+    for (int f = 0; f < n_frames; f++)
+        if (!g.frame(rgb8 + (size_t)f * width * height * 3, err)) return PT_ERR_IO;
+    g.end();
+    return PT_OK;
+}
 
 // ---- parity entry ----
 int pt_trace_batch(PtContext* c, int n, const float* rays6, int32_t* tri, float* t, float* bary2) {

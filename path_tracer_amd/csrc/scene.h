@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -74,10 +75,29 @@ void make_single_triangle(HostMesh& mesh);
 bool load_hdr(const char* path, HostImage& img, std::string& err);
 // Non-interlaced PNG of any colour type and bit depth, converted to 8-bit RGB.
 bool load_png_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
+// jpeg_decode.cpp: sequential and progressive Huffman-coded JPEG, 8-bit grey or YCbCr, to 8-bit RGB.
+bool load_jpeg_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
+// A map_Kd file by its signature: JPEG or PNG (the reference's stbi_load, src/cs488.h:839-846).
+bool load_texture_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
 bool save_png_rgb8(const char* path, const uint8_t* rgb, int w, int h, std::string& err);
 bool save_pfm(const char* path, const float* rgb_bottom_up, int w, int h, std::string& err);
 // Image::save quantisation (src/cs488.h:219-228): clamp to [0,1], scale by 255, truncate; rows top-down.
 void quantise_image(const float* rgb_bottom_up, int w, int h, std::vector<uint8_t>& out);
+// Animated GIF of 8-bit RGB frames (rows top-down), as the window's `F` recording produces
+// (src/cs488.h:255-266, 2297-2310): fixed 252-colour palette, ordered dither, delay in 1/100 s.
+class GifWriter {
+public:
+    ~GifWriter() { end(); }
+    bool begin(const char* path, int w, int h, int delay_cs, std::string& err);
+    bool frame(const uint8_t* rgb_top_down, std::string& err);
+    void end();
+    bool open() const { return fp_ != nullptr; }
+    int width() const { return w_; }
+    int height() const { return h_; }
+private:
+    FILE* fp_ = nullptr;
+    int w_ = 0, h_ = 0, delay_ = 1, frames_ = 0;
+};
 
 // ---- accel_build.cpp ----
 // threads: 0 = as many as the host offers, 1 = single-threaded; the tree does not depend on it

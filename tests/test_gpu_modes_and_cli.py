@@ -282,8 +282,17 @@ def test_cli_scripted_input(gpu_device, tmp_path):
     assert "(Recording started)" in r.stdout and "(Recording done)" in r.stdout
     names = sorted(os.listdir(tmp_path))
     stills = [n for n in names if re.fullmatch(r"output\d+\.png", n)]
-    recorded = [n for n in names if re.fullmatch(r"output\d+_\d{4}\.png", n)]
-    assert len(stills) == 1 and len(recorded) == 2          # frames 4 and 5 were recorded
+    recorded = [n for n in names if re.fullmatch(r"output\d+\.gif", n)]
+    assert len(stills) == 1 and len(recorded) == 1
+    from PIL import Image
+    gif = Image.open(tmp_path / recorded[0])
+    assert gif.size == (48, 36) and gif.n_frames == 2      # frames 4 and 5 were recorded
+    assert gif.info["duration"] == 10                       # globalGIFdelay = 1 hundredth (src/cs488.h:107)
+    gif.seek(1)                                             # the frame rendered as seq_0005 (same clamp and truncation)
+    want = np.asarray(Image.open(tmp_path / "seq_0005.png").convert("RGB")).astype(int)
+    got = np.asarray(gif.convert("RGB")).astype(int)
+    assert np.abs(got - want).max() <= 51                   # one step of the 6 x 7 x 6 palette
+    assert abs(got.mean() - want.mean()) < 2.0              # the ordered dither keeps the mean
     assert len([n for n in names if n.startswith("seq_")]) == 8 and "shot.pfm" in names
     # the generator is the reference's PCG32 (src/cs488.h:130-143): the I key at frame 2 comes after two per-frame draws
     _, vals, _ = orc.pcg32(3)

@@ -230,3 +230,106 @@ def test_obj_extensions_are_opt_in(tmp_path):
     obj2 = tmp_path / "penta.obj"
     obj2.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 2 0\nf 1 2 3 4 5\n")
     assert s2.load(str(obj2)) and s2.num_triangles() == 1
+
+
+def test_gif_encoder_round_trips_through_an_independent_decoder(tmp_path):
+    """The recording's container (src/cs488.h:255-266, 2297-2310 hand frames to a GIF writer): frame count,
+    size, delay and loop flag as written; pixels within one step of the fixed 6 x 7 x 6 palette, exact for
+    palette colours; an image large and noisy enough to fill the LZW table several times decodes too."""
+    from PIL import Image
+    import path_tracer_amd as pta
+    rng = np.random.default_rng(7)
+    h, w = 37, 53
+    frames = np.zeros((4, h, w, 3), np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    frames[0, ..., 0] = xx * 255 // (w - 1)
+    frames[0, ..., 1] = yy * 255 // (h - 1)
+    frames[0, ..., 2] = 128
+    frames[1] = rng.integers(0, 256, (h, w, 3))
+    frames[2] = 255
+    frames[3, ..., 0], frames[3, ..., 1], frames[3, ..., 2] = 51, 85, 204   # palette levels 1/5, 2/6, 4/5
+    path = str(tmp_path / "t.gif")
+    pta.encode_gif(path, frames, delay_cs=3)
+    im = Image.open(path)
+    assert im.format == "GIF" and im.size == (w, h) and im.n_frames == 4
+    assert im.info["duration"] == 30 and im.info["loop"] == 0
+    for f in range(4):
+        im.seek(f)
+        got = np.asarray(im.convert("RGB")).astype(int)
+        err = np.abs(got - frames[f].astype(int))
+        assert err[..., 0].max() <= 51 and err[..., 1].max() <= 43 and err[..., 2].max() <= 51
+        if f >= 2:
+            assert err.max() == 0
+    assert abs(float(np.asarray(Image.open(path).convert("RGB")).mean()) - float(frames[0].mean())) < 2.0
+    big = rng.integers(0, 256, (1, 300, 400, 3)).astype(np.uint8)
+    pta.encode_gif(str(tmp_path / "b.gif"), big)
+    got = np.asarray(Image.open(tmp_path / "b.gif").convert("RGB")).astype(int)
+    assert got.shape == (300, 400, 3) and np.abs(got - big[0].astype(int)).max() <= 51
+    with pytest.raises(pta.PtError):
+        pta.encode_gif(str(tmp_path / "no_such_dir" / "x.gif"), frames)
+
+
+def _texture_through_the_loader(tmp_path, file_name):
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 1 1\nmap_Kd %s\n" % file_name)
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nvn 0 0 1\nusemtl a\nf 1/1/1 2/2/1 3/3/1\n")
+    s = pta.Scene(pta.DEVICE_NONE)
+    assert s.load(str(tmp_path / "m.obj"))
+    try:
+        return s.get_texture(0), s.materials()[0]
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("shape", [(45, 70), (64, 64), (17, 9), (120, 201)])
+def test_jpeg_textures_decode_like_an_independent_decoder(tmp_path, shape):
+    """map_Kd files go through stbi_load in the reference (src/cs488.h:839-846), which reads baseline and
+    progressive JPEG.  No file of the reference holds a JPEG texture, so the check is against Pillow's
+    decoder on files written here: sequential and progressive, 4:4:4 / 4:2:2 / 4:2:0, optimised tables,
+    restart intervals, grey.  Decoders differ in the rounding of the inverse DCT, hence the small bar
+    (parity with stb_image itself is unpinned)."""
+    from PIL import Image
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([xx * 255 // (w - 1), yy * 255 // (h - 1), (xx + yy) * 255 // (w + h - 2)], -1).astype(np.uint8)
+    img[h // 4:h // 2, w // 5:w // 2] = [220, 30, 60]
+    img[::7, ::5] = 255
+    variants = {
+        "q95_444": dict(quality=95, subsampling=0),
+        "q75_420": dict(quality=75, subsampling=2),
+        "q85_422": dict(quality=85, subsampling=1),
+        "prog_444": dict(quality=90, subsampling=0, progressive=True),
+        "prog_420": dict(quality=80, subsampling=2, progressive=True),
+        "optimised": dict(quality=90, subsampling=0, optimize=True),
+        "restarts": dict(quality=85, subsampling=2, restart_marker_blocks=3),
+        "prog_restarts": dict(quality=85, subsampling=1, progressive=True, restart_marker_rows=1),
+    }
+    for name, kw in variants.items():
+        path = tmp_path / (name + ".jpg")
+        Image.fromarray(img).save(path, "JPEG", **kw)
+        got, mat = _texture_through_the_loader(tmp_path, name + ".jpg")
+        want = np.asarray(Image.open(path).convert("RGB")).astype(int)
+        assert got.shape == want.shape and mat.textured
+        err = np.abs(got.astype(int) - want)
+        assert err.max() <= 4 and err.mean() < 0.3, (name, int(err.max()), float(err.mean()))
+    Image.fromarray(img[..., 0], "L").save(tmp_path / "grey.jpg", "JPEG", quality=90)
+    got, _ = _texture_through_the_loader(tmp_path, "grey.jpg")
+    want = np.asarray(Image.open(tmp_path / "grey.jpg").convert("RGB")).astype(int)
+    assert np.abs(got.astype(int) - want).max() <= 2
+
+
+def test_broken_jpeg_texture_is_reported_and_left_empty(tmp_path, capfd):
+    """A texture that cannot be read leaves the material without pixels and prints the reference's
+    message (src/cs488.h:843); a truncated or non-JPEG file must not crash the decoder."""
+    from PIL import Image
+    img = (np.arange(64 * 64 * 3) % 251).astype(np.uint8).reshape(64, 64, 3)
+    Image.fromarray(img).save(tmp_path / "ok.jpg", "JPEG", quality=80)
+    blob = (tmp_path / "ok.jpg").read_bytes()
+    for name, data in (("cut.jpg", blob[:len(blob) // 3]), ("noise.jpg", b"\xff\xd8" + bytes(range(256)) * 4), ("empty.jpg", b"")):
+        (tmp_path / name).write_bytes(data)
+        if name == "cut.jpg":  # a truncated scan still yields the rows that were there
+            tex, mat = _texture_through_the_loader(tmp_path, name)
+            assert mat.textured and tex.shape == (64, 64, 3)
+            continue
+        with pytest.raises(pta.PtError):   # the material stays textured but holds no pixels
+            _texture_through_the_loader(tmp_path, name)
+        assert "Unable to load texture" in capfd.readouterr().err
