@@ -7,6 +7,8 @@ noise.  The bound used is 1.25 x the oracle-vs-oracle RMSE measured here with tw
 seeds, and the mean luminance must agree to 1 % (2 % for the scenes whose image is dominated by
 a few very bright texels).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -143,6 +145,19 @@ def test_full_size_frame_properties(gpu_device):
     o.render(spp=40, frames=1, threads=8)
     ref = o.image()
     assert abs(whole.mean() / 10.0 - ref.mean()) < 0.01 * ref.mean()
+
+
+@pytest.mark.timeout(900)
+def test_sample_split_into_external_buffers_with_frames_in_flight(gpu_device):
+    """The multi-GPU frame loop on one GPU (tests/check_external_accum.py: two contexts play ranks 0 and 1
+    of a sample split into caller-owned torch buffers, with two frames in flight each); run as a child
+    process because PyTorch has to open the GPU before this library does in a process that uses both."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "check_external_accum.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "external accumulation ok" in r.stdout
 
 
 def test_small_and_odd_shapes(gpu_device):
