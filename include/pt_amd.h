@@ -106,6 +106,9 @@ enum {
     PT_CNT_MAX_QUEUE = 6,   /* largest ray-queue population seen */
     PT_CNT_REPAIRED = 7,    /* batches rendered again in halves after their ray queues overflowed */
     PT_CNT_TAIL_RAYS = 8,   /* the part of PT_CNT_RAYS traced by the fused launch of the deep levels */
+    PT_CNT_WAVE_STEPS = 9,  /* node steps issued by wavefronts (each serves up to 64 rays: PT_CNT_BOX_TESTS / 2 /
+                               (64 x this) is the share of lanes at work in the node phase); needs PT_OPT_COUNT_TESTS */
+    PT_CNT_WAVE_ROUNDS = 10,/* triangle rounds issued by wavefronts, likewise against PT_CNT_TRI_TESTS */
     PT_CNT_COUNT = 12
 };
 

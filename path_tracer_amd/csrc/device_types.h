@@ -112,7 +112,7 @@ enum { TRACE_STACK = 64 };
 enum : int { EMPTY_LEAF = INT_MIN + 1 };
 
 enum { DC_RAYS = 0, DC_NAN = 1, DC_TAIL_RAYS = 2, DC_MAXQ = 3, DC_COUNT = 4 };
-enum { DB_HITS = 0, DB_BOX = 1, DB_TRI = 2, DB_OVERFLOW = 3, DC_BLOCK_COUNT = 4 };
+enum { DB_HITS = 0, DB_BOX = 1, DB_TRI = 2, DB_OVERFLOW = 3, DB_WAVE_STEPS = 4, DB_WAVE_ROUNDS = 5, DC_BLOCK_COUNT = 6 };
 
 struct LaunchCfg {
     hipStream_t stream;

@@ -1186,6 +1186,8 @@ int pt_get_counters(PtContext* c, uint64_t out[PT_CNT_COUNT]) {
     out[PT_CNT_SAMPLES] = c->samples_started;
     out[PT_CNT_NAN_SAMPLES] = d[DC_NAN];
     out[PT_CNT_HITS] = st[DB_HITS];
+    out[PT_CNT_WAVE_STEPS] = st[DB_WAVE_STEPS];
+    out[PT_CNT_WAVE_ROUNDS] = st[DB_WAVE_ROUNDS];
     out[PT_CNT_MAX_QUEUE] = d[DC_MAXQ];
     out[PT_CNT_REPAIRED] = c->repaired_batches;
     out[PT_CNT_TAIL_RAYS] = d[DC_TAIL_RAYS];

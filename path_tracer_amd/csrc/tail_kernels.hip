@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int 
                                                    int* __restrict__ qcount, unsigned long long* __restrict__ block_stats,
                                                    int leave_k) {
     extern __shared__ float4 lds_nodes[];
-    __shared__ __attribute__((aligned(16))) unsigned int s_stat[4];
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[8];
     __shared__ __attribute__((aligned(16))) int s_stack[LdsStack<KD>::ROWS * 256];
     __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LdsStack<KD>::ROWS * 256 : 4];
     __shared__ int s_out;

@@ -297,7 +297,7 @@ inline size_t dynamic_lds_bytes(const SceneGpu& sc) {
 template <bool KD>
 struct TraceLds {
     float4* nodes;          // dynamic LDS: lds_nodes node records, then (ALL_LDS) the leaf records
-    unsigned int* stat;     // 4: hits, slab tests, triangle tests, next ray of the region
+    unsigned int* stat;     // 6: hits, slab tests, triangle tests, next ray of the region, wave node steps, wave leaf rounds
     int* stack;             // LdsStack<KD>::ROWS * 256
     float* stack_t;         // the same number of entry distances (kd-tree only)
 };
@@ -334,12 +334,13 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     const int staged = sc.lds_nodes;
     float4* const lds_records = lds_nodes + 4 * staged;
     const int* const lds_refs = reinterpret_cast<const int*>(lds_records + 4 * sc.n_records);
-    if (threadIdx.x < 4) s_stat[threadIdx.x] = 0;
+    if (threadIdx.x < 6) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
     const vec3 rlo = v3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]);
     const vec3 rhi = v3(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2]);
     unsigned int n_box = 0, n_tri = 0, n_hit = 0;
+    unsigned int n_wave_steps = 0, n_wave_rounds = 0;  // COUNT: node steps and leaf rounds the wave issued (counted by one lane)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
@@ -444,6 +445,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             const int walking = __popcll(lane_mask(cur >= 0));
             if (walking == 0) break;
             if (leave_k > 0 && walking * leave_k < __popcll(lane_mask((unsigned int)cur > (unsigned int)NO_RAY))) break;
+            if (COUNT) n_wave_steps += lane == 0 ? 1 : 0;
             if (cur >= 0) {
                 float4 q0, q1, q2, q3;
                 if (ALL_LDS || cur < staged) {
@@ -490,6 +492,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     if (j > 0 && lane_mask(valid) == 0ull) break;
                     const int k = valid ? leaf_k + j : leaf_n - 1;
                     if (COUNT) n_tri += valid ? 1 : 0;
+                    if (COUNT) n_wave_rounds += lane == __ffsll((long long)lane_mask(true)) - 1 ? 1 : 0;
                     const float4* rec = ALL_LDS ? lds_records + 4 * lds_refs[off + 1 + k]
                                                 : sc.isect + 4 * (size_t)sc.refs[off + 1 + k];
                     triangle_round<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, valid, best);
@@ -504,6 +507,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                     if (j == 0) leaf_n = leaf_k == 0 ? __float_as_int(r1.w) : leaf_n;  // a leaf's first record carries its size
                     if (COUNT) n_tri += valid ? 1 : 0;
+                    if (COUNT) n_wave_rounds += lane == __ffsll((long long)lane_mask(true)) - 1 ? 1 : 0;
                     triangle_round<SLAB == SLAB_RECIP>(r0, r1, r2, r3, o, d, valid, best);
                 }
             }
@@ -514,20 +518,29 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     }
 
     // statistics: wave sums -> LDS -> this workgroup's own slots (no global atomics)
-    unsigned int tot_hit = n_hit, tot_box = n_box, tot_tri = n_tri;
+    unsigned int tot_hit = n_hit, tot_box = n_box, tot_tri = n_tri, tot_steps = n_wave_steps, tot_rounds = n_wave_rounds;
     for (int off = 32; off > 0; off >>= 1) {
         tot_hit += __shfl_down(tot_hit, off);
-        if (COUNT) { tot_box += __shfl_down(tot_box, off); tot_tri += __shfl_down(tot_tri, off); }
+        if (COUNT) {
+            tot_box += __shfl_down(tot_box, off); tot_tri += __shfl_down(tot_tri, off);
+            tot_steps += __shfl_down(tot_steps, off); tot_rounds += __shfl_down(tot_rounds, off);
+        }
     }
     if (lane == 0) {
         atomicAdd(&s_stat[0], tot_hit);
-        if (COUNT) { atomicAdd(&s_stat[1], tot_box); atomicAdd(&s_stat[2], tot_tri); }
+        if (COUNT) {
+            atomicAdd(&s_stat[1], tot_box); atomicAdd(&s_stat[2], tot_tri);
+            atomicAdd(&s_stat[4], tot_steps); atomicAdd(&s_stat[5], tot_rounds);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long* st = block_stats + (size_t)blk * DC_BLOCK_COUNT;
         st[DB_HITS] += s_stat[0];
-        if (COUNT) { st[DB_BOX] += s_stat[1]; st[DB_TRI] += s_stat[2]; }
+        if (COUNT) {
+            st[DB_BOX] += s_stat[1]; st[DB_TRI] += s_stat[2];
+            st[DB_WAVE_STEPS] += s_stat[4]; st[DB_WAVE_ROUNDS] += s_stat[5];
+        }
     }
 }
 

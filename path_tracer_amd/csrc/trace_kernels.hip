@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* _
                                                     const int* __restrict__ n_ptr, int n_fixed, int cap_block,
                                                     unsigned long long* __restrict__ block_stats, int leave_k) {
     extern __shared__ float4 lds_nodes[];
-    __shared__ __attribute__((aligned(16))) unsigned int s_stat[4];
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[8];
     __shared__ __attribute__((aligned(16))) int s_stack[LdsStack<KD>::ROWS * 256];
     __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LdsStack<KD>::ROWS * 256 : 4];
     const int blk = blockIdx.x;
