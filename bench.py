@@ -353,7 +353,7 @@ def main():
                 "workload": "%s %dx%d, %d spp/frame/GPU, SAH %s, progressive" % (
                     args.obj or WORKLOADS[args.workload][0] or "sponza stand-in (tools/make_sponza.py)", args.width, args.height,
                     args.spp, args.accel.upper()),
-                "frames_in_flight": streams,
+                "frames_in_flight": streams, "lane_streams_replaced": int(c[pta.CNT_STREAM_SWAPS]),
                 "parallelism": ("sample-split x%d + %s reduce of the accumulation buffer" % (
                     world, "RCCL" if args.backend == "nccl" else "gloo (host-staged rehearsal)")) if world > 1 else "single GPU",
             },

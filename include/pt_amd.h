@@ -109,6 +109,8 @@ enum {
     PT_CNT_WAVE_STEPS = 9,  /* node steps issued by wavefronts (each serves up to 64 rays: PT_CNT_BOX_TESTS / 2 /
                                (64 x this) is the share of lanes at work in the node phase); needs PT_OPT_COUNT_TESTS */
     PT_CNT_WAVE_ROUNDS = 10,/* triangle rounds issued by wavefronts, likewise against PT_CNT_TRI_TESTS */
+    PT_CNT_STREAM_SWAPS = 11,/* internal streams replaced because they ran in order with another stream of the context
+                               (hardware queue shared; see PT_OPT_STREAMS); not reset by pt_reset_counters */
     PT_CNT_COUNT = 12
 };
 

@@ -24,7 +24,7 @@ ERR_INVALID_ARG, ERR_IO, ERR_INVALID_OBJ, ERR_NOT_READY, ERR_HIP, ERR_QUEUE_OVER
 OPT_SEED, OPT_MAX_LEVEL, OPT_COUNT_TESTS, OPT_PROFILE, OPT_MAX_BATCH, OPT_QUEUE_FACTOR, OPT_LDS_NODES, OPT_TRAVERSAL, OPT_TAIL_LEVEL, OPT_BUILD_THREADS, OPT_OBJ_EXTENDED, OPT_BLOCKS_PER_CU, OPT_STREAMS = (
     range(1, 14))
 CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SAMPLES, CNT_NAN_SAMPLES, CNT_HITS, CNT_MAX_QUEUE, CNT_REPAIRED, CNT_TAIL_RAYS = range(9)
-CNT_WAVE_STEPS, CNT_WAVE_ROUNDS = 9, 10
+CNT_WAVE_STEPS, CNT_WAVE_ROUNDS, CNT_STREAM_SWAPS = 9, 10, 11
 CNT_COUNT = 12
 TIMER_RAYGEN, TIMER_TRACE, TIMER_SHADE, TIMER_ACCUM, TIMER_TAIL = range(5)
 TIMER_COUNT = 5

@@ -140,6 +140,8 @@ hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const 
 hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, int tail_level, unsigned long long* totals);
 hipError_t launch_resolve(const LaunchCfg& cfg, const float* accum, float* frame, int n_pixels, int total_samples);
 hipError_t launch_clear(const LaunchCfg& cfg, float* buf, size_t n);
+// a single wave that stays busy for about `microseconds` (to probe whether two streams overlap)
+hipError_t launch_spin(const LaunchCfg& cfg, int microseconds);
 // unpacks rays6 (n x 6 floats) into queue form for the batch-trace entry
 hipError_t launch_pack_rays(const LaunchCfg& cfg, const float* rays6, int n, float4* ray_o, float4* ray_d);
 hipError_t launch_unpack_hits(const LaunchCfg& cfg, const float4* hit, int n, int* tri, float* t, float* bary2);

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -132,6 +133,8 @@ struct PtContext {
     float* ext_accum = nullptr;
     Lane lanes[MAX_LANES];
     int n_lanes = 2;                      // batches in flight (PT_OPT_STREAMS)
+    bool lanes_checked = false;           // the lanes' streams have been probed for running side by side
+    int lane_stream_swaps = 0;            // streams replaced by that probe
     DeviceBuffer<unsigned long long> d_totals;
     DeviceBuffer<unsigned long long> d_block_stats;  // of pt_trace_batch (the lanes have their own)
     DeviceBuffer<int> d_batch_flags;      // FLAG_RING overflow flags, one per batch in flight
@@ -501,6 +504,49 @@ int clear_block_stats(PtContext* c) {
     return PT_OK;
 }
 
+// Do two streams run side by side?  A process's streams are mapped onto a few hardware queues
+// (GPU_MAX_HW_QUEUES), and two that share one run in order.  Two 150-us single-wave kernels take
+// 150 us when they overlap and 300 when they do not.
+bool streams_overlap(PtContext* c, hipStream_t a, hipStream_t b) {
+    LaunchCfg ka = cfg_of(c), kb = cfg_of(c);
+    ka.stream = a; kb.stream = b;
+    const int us = 150;
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)launch_spin(ka, us);
+    (void)launch_spin(kb, us);
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    const double elapsed = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return elapsed < 1.6 * us;
+}
+
+// The overlap of consecutive batches needs the lanes' streams and the context's stream on hardware
+// queues of their own.  Which queue a new stream gets is the runtime's business, so the lanes are
+// probed once (and again after pt_set_stream) and a lane whose stream runs in order with the
+// context's stream or with an earlier lane gets a new stream -- created while the old one still
+// exists, so that it lands elsewhere -- a few times at most.  Only speed depends on this.
+int check_lanes(PtContext* c) {
+    c->lanes_checked = true;
+    if (c->n_lanes < 2) return PT_OK;
+    for (int l = 0; l < c->n_lanes; l++) {
+        Lane& ln = c->lanes[l];
+        if (!ln.stream) continue;
+        for (int attempt = 0; attempt < 6; attempt++) {
+            bool clash = !streams_overlap(c, ln.stream, c->stream);
+            for (int m = 0; m < l && !clash; m++)
+                if (c->lanes[m].stream) clash = !streams_overlap(c, ln.stream, c->lanes[m].stream);
+            if (!clash) break;
+            hipStream_t fresh = nullptr;
+            PT_HIP(c, hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+            (void)hipStreamSynchronize(ln.stream);
+            (void)hipStreamDestroy(ln.stream);
+            ln.stream = fresh;
+            c->lane_stream_swaps++;
+        }
+    }
+    return PT_OK;
+}
+
 // One wavefront batch: camera rays, then trace + shade per bounce level on the batch's lane, then
 // accumulate on the context's stream.
 int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int sample0, int chunk) {
@@ -512,8 +558,13 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     const bool own_stream = c->n_lanes > 1;
     {
         const size_t need = (size_t)b.n_slots > c->batch_hint ? (size_t)b.n_slots : c->batch_hint;
-        const int rc = ensure_lane(c, ln, need);
+        int rc = ensure_lane(c, ln, need);
         if (rc != PT_OK) return rc;
+        if (own_stream && !c->lanes_checked) {  // once: every lane's stream, then the probe for hardware queues of their own
+            for (int l = 0; l < c->n_lanes && rc == PT_OK; l++) rc = ensure_lane(c, c->lanes[l], need);
+            if (rc == PT_OK) rc = check_lanes(c);
+            if (rc != PT_OK) return rc;
+        }
     }
     // workgroups sharing the batch: about 2048 camera samples each, at most the resident grid
     int nb = (b.n_slots + 2047) / 2048;
@@ -753,6 +804,7 @@ int pt_set_stream(PtContext* c, void* hip_stream) {
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
+    c->lanes_checked = false;  // the lanes have to stand clear of this stream's hardware queue too
     return PT_OK;
 }
 
@@ -793,7 +845,7 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
         case PT_OPT_STREAMS:
             if (value < 1 || value > MAX_LANES) return fail(c, PT_ERR_INVALID_ARG, "between 1 and 4 batches in flight");
             if (c->device != PT_DEVICE_NONE && c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
-            c->n_lanes = (int)value; break;
+            c->n_lanes = (int)value; c->lanes_checked = false; break;
         case PT_OPT_TAIL_LEVEL:
             if (value > 64 && value != 255) return fail(c, PT_ERR_INVALID_ARG, "tail level above 64");
             c->tail_level = (int)value; break;
@@ -1186,6 +1238,7 @@ int pt_get_counters(PtContext* c, uint64_t out[PT_CNT_COUNT]) {
     out[PT_CNT_SAMPLES] = c->samples_started;
     out[PT_CNT_NAN_SAMPLES] = d[DC_NAN];
     out[PT_CNT_HITS] = st[DB_HITS];
+    out[PT_CNT_STREAM_SWAPS] = (uint64_t)c->lane_stream_swaps;
     out[PT_CNT_WAVE_STEPS] = st[DB_WAVE_STEPS];
     out[PT_CNT_WAVE_ROUNDS] = st[DB_WAVE_ROUNDS];
     out[PT_CNT_MAX_QUEUE] = d[DC_MAXQ];

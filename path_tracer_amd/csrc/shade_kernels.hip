@@ -149,7 +149,19 @@ __global__ void clear_kernel(float* buf, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) buf[i] = 0.0f;
 }
 
+// One wave that keeps its CU busy for a given time (100 MHz wall clock); the host uses pairs of
+// these to find out whether two streams run side by side.  Bounded by an iteration count as well.
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    for (int i = 0; i < (1 << 24) && wall_clock64() - t0 < ticks; i++) {}
+}
+
 }  // namespace
+
+hipError_t launch_spin(const LaunchCfg& cfg, int microseconds) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cfg.stream, (long long)microseconds * 100);
+    return hipGetLastError();
+}
 
 hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const BatchGpu& batch, QueueSet out,
                          float4* sample_rad, int* qcount) {
