@@ -46,3 +46,20 @@ def test_null_and_host_only_contexts():
 
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(pta.PtMaterial) == 96 + 4 + 4 + 48 + 12 + 12
+
+
+def test_python_constants_equal_the_header_enums():
+    """Every PT_OPT_ / PT_CNT_ / PT_TIMER_ value of the header under the binding's name without the PT_ prefix."""
+    text = open(os.path.join(ROOT, "include", "pt_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    pairs = re.findall(r"\bPT_((?:OPT|CNT|TIMER)_[A-Z_]+)\s*=\s*(\d+)", text)
+    assert len(pairs) >= 30
+    for name, value in pairs:
+        assert getattr(pta, name) == int(value), name
+    v = ctypes.c_uint64()
+    h = ctypes.c_void_p()
+    L = pta.lib()
+    assert L.pt_create(pta.DEVICE_NONE, ctypes.byref(h)) == pta.PT_OK
+    assert L.pt_get_option(h, pta.OPT_STREAMS, ctypes.byref(v)) == pta.PT_OK and v.value == 2
+    assert L.pt_set_option(h, pta.OPT_STREAMS, ctypes.c_uint64(5)) == pta.ERR_INVALID_ARG
+    L.pt_destroy(h)
