@@ -616,7 +616,8 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     // fused kernel keeps fewer waves resident, which shows where node fetches come from memory)
     const bool in_lds = c->scene.lds_nodes >= c->scene.n_nodes;
     const bool light_shading = c->scene.shading_kind == 2;  // SHADE_PLAIN: the fused kernel keeps the walk's occupancy
-    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading ? 1 : 6) : 8) : c->tail_level;
+    // (with a second batch in flight the launch gaps that the early hand-over saved are filled anyway: 6 is 3 % faster then)
+    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : 6) : 8) : c->tail_level;
     const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
     const int split = fuse ? tail : levels;
     for (int level = 0; level < split; level++) {

@@ -254,7 +254,7 @@ def test_frames_in_flight_do_not_change_the_image(gpu_device, obj, accel):
             assert np.array_equal(acc, ref_acc)
             for a, b in zip(frames, ref_frames):
                 assert np.array_equal(a, b)
-            assert list(c[:9]) == list(ref_c[:9])
+            assert list(c[:8]) == list(ref_c[:8])   # rays, tests, samples, hits ...; where the fused launch takes over may differ
     s = load_gpu_scene(obj, accel)
     with pytest.raises(Exception):
         s.set_option(pta.OPT_STREAMS, 5)
