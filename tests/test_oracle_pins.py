@@ -5,8 +5,9 @@ pinned by what is available:
   * statistics measured on the compiled reference when this project was surveyed (tree sizes,
     rays per sample, slab/triangle tests per ray, path-depth profile of the Cornell box; tree
     sizes of the teapot) -- the oracle must reproduce them;
-  * the converged screenshots the reference holds (project_demo/path_tracing), copied as data
-    under tests/golden/screenshots -- a statistical pin of the whole estimator;
+  * the screenshots the reference holds of the finished path tracer (project_demo/path_tracing,
+    area_lights, microfacets), copied as data under tests/golden/screenshots -- a statistical pin of
+    the whole estimator for Lambertian, glass and GGX metal surfaces;
   * structural properties of its generator and camera.
 Bit-level parity with the reference remains unpinned.
 """
@@ -83,23 +84,42 @@ def test_single_thread_render_is_reproducible_and_accel_independent():
     assert np.array_equal(imgs[0], imgs[1])
 
 
-@pytest.mark.parametrize("obj,shot,spp_frames,bound", [
-    ("cornellbox.obj", "cornellbox_15000spp.png", 16, 0.06),
-    ("cornellbox-glass.obj", "cornellbox-glass_7200spp.png", 16, 0.06),
+def _blocks(img):
+    """16 x 16 block means of a 384 x 512 image: what is left of an image once the noise is averaged out."""
+    return img.reshape(384 // 16, 16, 512 // 16, 16, 3).mean((1, 3))
+
+
+@pytest.mark.parametrize("obj,shot,roughness,spp_frames,bound", [
+    ("cornellbox.obj", "cornellbox_15000spp.png", None, 16, 0.06),
+    ("cornellbox.obj", "cornellbox_19720spp.png", None, 8, 0.075),
+    ("cornellbox-glass.obj", "cornellbox-glass_7200spp.png", None, 16, 0.06),
+    ("cornellbox-metal.obj", "cornellbox_roughness_0.1.png", 0.1, 8, 0.075),
+    ("cornellbox-metal.obj", "cornellbox_roughness_0.3.png", 0.3, 8, 0.075),
+    ("cornellbox-metal.obj", "cornellbox_roughness_0.5.png", 0.5, 8, 0.075),
 ])
-def test_converges_to_reference_screenshot(obj, shot, spp_frames, bound):
-    """The oracle's 160-spp render against the reference's own converged 512x384 screenshot
-    (8-bit, clamped to [0,1]).  160 spp of noise alone give an RMSE near 0.05 after clamping; a
-    wrong estimator (missing bounce, unweighted roulette, wrong light power) moves the mean."""
+def test_converges_to_reference_screenshot(obj, shot, roughness, spp_frames, bound):
+    """The oracle's render against the reference's own 512x384 screenshots (8-bit, clamped to [0,1]):
+    project_demo/path_tracing (Lambertian, glass), area_lights, and microfacets/cornellbox_roughness_*
+    (cornellbox-metal.obj with the metal's Ro set to 0.1 / 0.3 / 0.5: the three differ in mean by 16 % and
+    3 %, so the GGX sampling and the Cook-Torrance term are pinned, not just the scene).  Noise alone gives
+    an RMSE near 0.05-0.07 at these sample counts; the 16 x 16 block means and the image mean have to agree
+    closely, and a wrong estimator (missing bounce, unweighted roulette, wrong light power, wrong lobe) moves them."""
     from PIL import Image
     ref = np.asarray(Image.open(os.path.join(GOLDEN, "screenshots", shot)).convert("RGB"), np.float32)[::-1] / 255.0
     o = load_oracle_scene(obj, orc.BVH)
+    if roughness is not None:
+        metals = [i for i, m in enumerate(o.materials()) if m.type == orc.METAL]
+        assert len(metals) == 1
+        o.set_material(metals[0], roughness=roughness)
+        o.build(orc.BVH)
     o.reset(512, 384)
     o.render(spp=10, frames=spp_frames, threads=8)
     mine = np.floor(np.clip(o.image(), 0, 1) * 255.0) / 255.0
     err = float(np.sqrt(np.mean((mine - ref) ** 2)))
     assert err < bound, err
     assert abs(mine.mean() - ref.mean()) < 0.015 * ref.mean() + 0.002, (mine.mean(), ref.mean())
+    block_err = float(np.sqrt(np.mean((_blocks(mine) - _blocks(ref)) ** 2)))
+    assert block_err < 0.012, block_err
 
 
 def test_camera_rays_follow_the_film_model():
