@@ -167,6 +167,7 @@ def test_sample_split_into_external_buffers_with_frames_in_flight(gpu_device):
     ("cornellbox-metal.obj", "cornellbox_roughness_0.1.png", 0.1),
     ("cornellbox-metal.obj", "cornellbox_roughness_0.3.png", 0.3),
     ("cornellbox-metal.obj", "cornellbox_roughness_0.5.png", 0.5),
+    ("cornellbox-alpha.obj", "cornellbox-alpha_purple.png", None),   # alpha_blending/alpha_purple.png: the file as shipped
 ])
 def test_gpu_render_against_the_reference_screenshots(gpu_device, obj, shot, roughness):
     """The GPU path against the reference's own output, without the oracle in between: 2000 spp at the
@@ -196,7 +197,7 @@ def test_gpu_render_against_the_reference_screenshots(gpu_device, obj, shot, rou
 
     assert abs(mine.mean() - ref.mean()) < 0.006 * ref.mean(), (mine.mean(), ref.mean())
     block_err = float(np.sqrt(np.mean((blocks(mine) - blocks(ref)) ** 2)))
-    assert block_err < 0.003, block_err
+    assert block_err < (0.004 if "alpha" in shot else 0.003), block_err   # the alpha screenshot is the noisiest
     assert float(np.sqrt(np.mean((mine - ref) ** 2))) < 0.03
 
 
