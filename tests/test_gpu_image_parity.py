@@ -168,6 +168,7 @@ def test_sample_split_into_external_buffers_with_frames_in_flight(gpu_device):
     ("cornellbox-metal.obj", "cornellbox_roughness_0.3.png", 0.3),
     ("cornellbox-metal.obj", "cornellbox_roughness_0.5.png", 0.5),
     ("cornellbox-alpha.obj", "cornellbox-alpha_purple.png", None),   # alpha_blending/alpha_purple.png: the file as shipped
+    ("cornellbox-demo.obj", "cornellbox-demo_best.png", None),       # project_demo/best.png: metal wall, glass box, all shading kinds
 ])
 def test_gpu_render_against_the_reference_screenshots(gpu_device, obj, shot, roughness):
     """The GPU path against the reference's own output, without the oracle in between: 2000 spp at the

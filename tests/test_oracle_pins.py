@@ -97,6 +97,7 @@ def _blocks(img):
     ("cornellbox-metal.obj", "cornellbox_roughness_0.3.png", 0.3, 8, 0.075),
     ("cornellbox-metal.obj", "cornellbox_roughness_0.5.png", 0.5, 8, 0.075),
     ("cornellbox-alpha.obj", "cornellbox-alpha_purple.png", None, 8, 0.085),   # alpha_blending/alpha_purple.png
+    ("cornellbox-demo.obj", "cornellbox-demo_best.png", None, 8, 0.085),        # project_demo/best.png
 ])
 def test_converges_to_reference_screenshot(obj, shot, roughness, spp_frames, bound):
     """The oracle's render against the reference's own 512x384 screenshots (8-bit, clamped to [0,1]):

@@ -6,7 +6,7 @@ sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import path_tracer_amd as pta, orc
 from common import load_gpu_scene, GOLDEN
 from PIL import Image
-for obj,shot,ro in (("cornellbox.obj","cornellbox_15000spp.png",None),("cornellbox.obj","cornellbox_19720spp.png",None),("cornellbox-glass.obj","cornellbox-glass_7200spp.png",None),("cornellbox-metal.obj","cornellbox_roughness_0.1.png",0.1),("cornellbox-metal.obj","cornellbox_roughness_0.3.png",0.3),("cornellbox-metal.obj","cornellbox_roughness_0.5.png",0.5),("cornellbox-alpha.obj","cornellbox-alpha_purple.png",None)):
+for obj,shot,ro in (("cornellbox.obj","cornellbox_15000spp.png",None),("cornellbox.obj","cornellbox_19720spp.png",None),("cornellbox-glass.obj","cornellbox-glass_7200spp.png",None),("cornellbox-metal.obj","cornellbox_roughness_0.1.png",0.1),("cornellbox-metal.obj","cornellbox_roughness_0.3.png",0.3),("cornellbox-metal.obj","cornellbox_roughness_0.5.png",0.5),("cornellbox-alpha.obj","cornellbox-alpha_purple.png",None),("cornellbox-demo.obj","cornellbox-demo_best.png",None)):
     ref=np.asarray(Image.open(os.path.join(GOLDEN,"screenshots",shot)).convert("RGB"),np.float32)[::-1]/255.0
     s=load_gpu_scene(obj, orc.BVH)
     if ro is not None:
