@@ -173,7 +173,7 @@ def test_sample_split_into_external_buffers_with_frames_in_flight(gpu_device):
 def test_gpu_render_against_the_reference_screenshots(gpu_device, obj, shot, roughness):
     """The GPU path against the reference's own output, without the oracle in between: 2000 spp at the
     screenshots' 512 x 384 (project_demo/path_tracing, area_lights, microfacets with the metal's Ro set to the
-    value in the file name), quantised like Image::save.  The image mean within 0.6 % (measured: 0.03 %, glass
+    value in the file name), quantised like Image::save.  The image mean within 0.8 % (measured: 0.03 %, glass
     0.4 %) and the 16 x 16 block means within 0.003 RMS (measured 0.0007-0.0013); per pixel the RMSE is about
     0.01-0.017, the screenshots' own noise and 8-bit steps."""
     from PIL import Image
@@ -196,7 +196,7 @@ def test_gpu_render_against_the_reference_screenshots(gpu_device, obj, shot, rou
     def blocks(img):
         return img.reshape(384 // 16, 16, 512 // 16, 16, 3).mean((1, 3))
 
-    assert abs(mine.mean() - ref.mean()) < 0.006 * ref.mean(), (mine.mean(), ref.mean())
+    assert abs(mine.mean() - ref.mean()) < 0.008 * ref.mean(), (mine.mean(), ref.mean())
     block_err = float(np.sqrt(np.mean((blocks(mine) - blocks(ref)) ** 2)))
     assert block_err < (0.004 if "alpha" in shot else 0.003), block_err   # the alpha screenshot is the noisiest
     assert float(np.sqrt(np.mean((mine - ref) ** 2))) < 0.03
