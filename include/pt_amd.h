@@ -30,7 +30,9 @@ typedef enum PtStatus {
     PT_ERR_HIP = -5,          /* a HIP runtime call failed; see pt_last_error */
     PT_ERR_QUEUE_OVERFLOW = -6, /* forked paths outgrew the ray queues even for a batch of 64 samples */
     PT_ERR_TREE_DEPTH = -7,   /* accelerator deeper than the traversal stack */
-    PT_ERR_UNSUPPORTED = -8
+    PT_ERR_UNSUPPORTED = -8,
+    PT_ERR_NO_MEMORY = -9,    /* host allocation failed (or another C++ exception was caught at the boundary) */
+    PT_ERR_RCCL = -10         /* an RCCL call failed; see pt_last_error */
 } PtStatus;
 
 /* Accelerator kinds: the reference selects one at compile time with `#define KD_TREE`

@@ -20,6 +20,7 @@ DEVICE_NONE = -1
 PT_OK = 0
 ERR_INVALID_ARG, ERR_IO, ERR_INVALID_OBJ, ERR_NOT_READY, ERR_HIP, ERR_QUEUE_OVERFLOW, ERR_TREE_DEPTH, ERR_UNSUPPORTED = (
     -1, -2, -3, -4, -5, -6, -7, -8)
+ERR_NO_MEMORY, ERR_RCCL = -9, -10
 
 OPT_SEED, OPT_MAX_LEVEL, OPT_COUNT_TESTS, OPT_PROFILE, OPT_MAX_BATCH, OPT_QUEUE_FACTOR, OPT_LDS_NODES, OPT_TRAVERSAL, OPT_TAIL_LEVEL, OPT_BUILD_THREADS, OPT_OBJ_EXTENDED, OPT_BLOCKS_PER_CU, OPT_STREAMS = (
     range(1, 14))

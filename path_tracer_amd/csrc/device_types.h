@@ -137,7 +137,9 @@ hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchG
 hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const float4* sample_rad, float* accum,
                              unsigned long long* totals);
 // sums the per-workgroup queue counts of every level of a finished batch into totals
-hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, int tail_level, unsigned long long* totals);
+// (nothing is added for a batch whose overflow flag is set: its pieces are tallied when they are rendered again)
+hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, int tail_level, const int* overflow,
+                        unsigned long long* totals);
 hipError_t launch_resolve(const LaunchCfg& cfg, const float* accum, float* frame, int n_pixels, int total_samples);
 hipError_t launch_clear(const LaunchCfg& cfg, float* buf, size_t n);
 // a single wave that stays busy for about `microseconds` (to probe whether two streams overlap)

@@ -85,6 +85,7 @@ bool load_hdr(const char* path, HostImage& img, std::string& err) {
         err = "unsupported Radiance orientation";
         return false;
     }
+    if (w > 32768 || h > 32768) { err = "Radiance image larger than 32768 pixels a side"; return false; }
     std::vector<uint8_t> texels((size_t)w * h * 4);
     const uint8_t* p = buf.data() + pos;
     const uint8_t* end = buf.data() + buf.size();
@@ -154,6 +155,7 @@ bool load_png_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, 
         pos += 12 + (size_t)n;
     }
     if (!have_ihdr || w <= 0 || h <= 0) { err = "PNG without header"; return false; }
+    if (w > 32768 || h > 32768) { err = "PNG larger than 32768 pixels a side"; return false; }
     if (interlace) { err = "interlaced PNG is not supported"; return false; }
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels || (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)) { err = "unsupported PNG layout"; return false; }

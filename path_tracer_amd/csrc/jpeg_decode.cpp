@@ -177,6 +177,7 @@ struct Decoder {
         const int n = read_u8();
         if (precision != 8) return fail("only 8-bit JPEG samples are supported");
         if (width <= 0 || height <= 0) return fail("JPEG without a size");
+        if (width > 16384 || height > 16384) return fail("JPEG larger than 16384 pixels a side");
         if (n != 1 && n != 3) return fail("only grey and YCbCr JPEG files are supported");
         if (len != 6 + 3 * n) return fail("bad frame header");
         comps.resize((size_t)n);

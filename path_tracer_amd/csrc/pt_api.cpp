@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -142,6 +144,10 @@ struct PtContext {
     uint64_t batch_seq = 0, repaired_batches = 0;
     size_t batch_hint = 0;                // samples of the largest batch of the frame being rendered
     uint64_t batch_rays = 0;  // rays traced through pt_trace_batch
+    // staging of pt_trace_batch, kept between calls and grown on demand
+    DeviceBuffer<float> tb_rays, tb_t, tb_bary;
+    DeviceBuffer<int> tb_tri;
+    DeviceBuffer<float4> tb_o, tb_d, tb_h;
 
     GifWriter recording;
 
@@ -171,6 +177,20 @@ int fail(PtContext* c, int code, const std::string& msg) {
             return fail(ctx, PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));     \
     } while (0)
 
+// No exception crosses the C boundary: the bodies of the entry points that allocate host memory or
+// start threads run inside PT_TRY / PT_CATCH.
+#define PT_TRY try {
+#define PT_CATCH(ctx)                                                                             \
+    }                                                                                             \
+    catch (const std::bad_alloc&) { return fail_noexcept(ctx, PT_ERR_NO_MEMORY, "out of host memory"); }     \
+    catch (const std::exception& e__) { return fail_noexcept(ctx, PT_ERR_NO_MEMORY, e__.what()); }            \
+    catch (...) { return fail_noexcept(ctx, PT_ERR_NO_MEMORY, "unexpected exception"); }
+
+int fail_noexcept(PtContext* c, int code, const char* msg) noexcept {
+    try { if (c) c->error = msg; } catch (...) {}
+    return code;
+}
+
 LaunchCfg cfg_of(PtContext* c) {
     LaunchCfg k;
     k.stream = c->stream;
@@ -185,7 +205,7 @@ hipEvent_t take_event(PtContext* c) {
         return e;
     }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) e = nullptr;  // the span is then left out (ScopedTimer)
     return e;
 }
 
@@ -201,6 +221,12 @@ struct ScopedTimer {
         span.timer = timer;
         span.start = take_event(c);
         span.stop = take_event(c);
+        if (!span.start || !span.stop) {  // no event to be had: this launch goes untimed
+            if (span.start) c->event_pool.push_back(span.start);
+            if (span.stop) c->event_pool.push_back(span.stop);
+            on = false;
+            return;
+        }
         (void)hipEventRecord(span.start, stream);
     }
     ~ScopedTimer() {
@@ -646,7 +672,7 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     {
         ScopedTimer tm(c, PT_TIMER_ACCUM);
         PT_HIP(c, launch_accumulate(image_cfg, b, ln.d_sample_rad.ptr, c->accum_ptr(), c->d_totals.ptr));
-        PT_HIP(c, launch_tally(image_cfg, ln.d_qcount.ptr, levels, nb, split, c->d_totals.ptr));
+        PT_HIP(c, launch_tally(image_cfg, ln.d_qcount.ptr, levels, nb, split, b.overflow, c->d_totals.ptr));
     }
     if (own_stream) PT_HIP(c, hipEventRecord(ln.consumed[turn], c->stream));
     c->samples_started += (uint64_t)b.n_slots;
@@ -746,7 +772,8 @@ int pt_create(int device, PtContext** out) {
     if (!out) return PT_ERR_INVALID_ARG;
     *out = nullptr;
     if (device == PT_DEVICE_NONE) {  // scene and tree construction only; nothing here can render
-        PtContext* h = new PtContext();
+        PtContext* h = new (std::nothrow) PtContext();
+        if (!h) return PT_ERR_NO_MEMORY;
         h->device = PT_DEVICE_NONE;
         *out = h;
         return PT_OK;
@@ -754,7 +781,8 @@ int pt_create(int device, PtContext** out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PT_ERR_HIP;
     if (hipSetDevice(device) != hipSuccess) return PT_ERR_HIP;
-    PtContext* c = new PtContext();
+    PtContext* c = new (std::nothrow) PtContext();
+    if (!c) return PT_ERR_NO_MEMORY;
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PT_ERR_HIP; }
     c->own_stream = true;
@@ -791,6 +819,7 @@ void pt_destroy(PtContext* c) {
         ln.release();
     }
     c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release();
+    c->tb_rays.release(); c->tb_t.release(); c->tb_bary.release(); c->tb_tri.release(); c->tb_o.release(); c->tb_d.release(); c->tb_h.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -810,6 +839,7 @@ int pt_set_stream(PtContext* c, void* hip_stream) {
 }
 
 int pt_set_option(PtContext* c, int option, uint64_t value) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     if (!c->issued.empty()) {  // batches in flight are completed under the settings they started with
         int rc = settle(c);
@@ -835,7 +865,10 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             c->lds_nodes_opt = value == 65535 ? -1 : (int)value;
             if (c->built) choose_lds_nodes(c);
             break;
-        case PT_OPT_TRAVERSAL: c->traversal = (int)value; c->resident_per_cu = 0; break;
+        case PT_OPT_TRAVERSAL:
+            // a wave has 64 lanes: a refill threshold above that could never be met and the walk would not end
+            if (value > 0x7fff || ((value >> 8) & 127) > 64) return fail(c, PT_ERR_INVALID_ARG, "traversal bits 8..14 (refill threshold) above 64, or unknown bits");
+            c->traversal = (int)value; c->resident_per_cu = 0; break;
         case PT_OPT_OBJ_EXTENDED: c->obj_extended = value != 0; break;
         case PT_OPT_BLOCKS_PER_CU:
             if (value > 8) return fail(c, PT_ERR_INVALID_ARG, "at most 8 workgroups per CU");
@@ -853,6 +886,7 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_get_option(PtContext* c, int option, uint64_t* value) {
@@ -878,6 +912,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
 
 // ---- scene ----
 int pt_load_obj(PtContext* c, const char* path) {
+    PT_TRY
     if (!c || !path) return PT_ERR_INVALID_ARG;
     c->built = false;
     std::string err;
@@ -888,16 +923,20 @@ int pt_load_obj(PtContext* c, const char* path) {
         return fail(c, PT_ERR_INVALID_OBJ, err);
     }
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_single_triangle(PtContext* c) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     c->built = false;
     make_single_triangle(c->mesh);
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_load_env(PtContext* c, const char* path) {
+    PT_TRY
     if (!c || !path) return PT_ERR_INVALID_ARG;
     std::string err;
     HostImage img;
@@ -905,9 +944,11 @@ int pt_load_env(PtContext* c, const char* path) {
     c->env = img;
     c->built = false;
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_set_mesh(PtContext* c, int n, const float* pos9, const float* nrm9, const float* uv6, const int32_t* matid) {
+    PT_TRY
     if (!c || n <= 0 || !pos9 || !nrm9) return fail(c, PT_ERR_INVALID_ARG, "pt_set_mesh: bad arguments");
     c->built = false;
     c->mesh.pos.assign(pos9, pos9 + 9 * (size_t)n);
@@ -916,17 +957,21 @@ int pt_set_mesh(PtContext* c, int n, const float* pos9, const float* nrm9, const
     if (matid) c->mesh.mat.assign(matid, matid + n); else c->mesh.mat.assign(n, 0);
     if (c->mesh.materials.empty()) c->mesh.materials.resize(1);
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_set_materials(PtContext* c, int n, const PtMaterial* mats) {
+    PT_TRY
     if (!c || n <= 0 || !mats) return fail(c, PT_ERR_INVALID_ARG, "pt_set_materials: bad arguments");
     c->built = false;
     c->mesh.materials.resize(n);
     for (int i = 0; i < n; i++) from_public(mats[i], c->mesh.materials[i]);
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_set_texture(PtContext* c, int material, const uint8_t* rgb, int w, int h) {
+    PT_TRY
     if (!c || !rgb || w <= 0 || h <= 0 || material < 0 || material >= (int)c->mesh.materials.size())
         return fail(c, PT_ERR_INVALID_ARG, "pt_set_texture: bad arguments");
     HostMaterial& m = c->mesh.materials[material];
@@ -935,9 +980,11 @@ int pt_set_texture(PtContext* c, int material, const uint8_t* rgb, int w, int h)
     m.textured = true;
     c->built = false;
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_set_env(PtContext* c, const float* rgb, int w, int h) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     c->built = false;
     if (!rgb || w <= 0 || h <= 0) { c->env = HostImage(); return PT_OK; }
@@ -945,6 +992,7 @@ int pt_set_env(PtContext* c, const float* rgb, int w, int h) {
     c->env.rgb.resize((size_t)w * h * 3);
     for (int y = 0; y < h; y++) memcpy(&c->env.rgb[(size_t)(h - 1 - y) * w * 3], rgb + (size_t)y * w * 3, sizeof(float) * 3 * (size_t)w);
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_num_triangles(PtContext* c) { return c ? c->mesh.num_tris() : PT_ERR_INVALID_ARG; }
@@ -961,9 +1009,11 @@ int pt_get_mesh(PtContext* c, float* pos9, float* nrm9, float* uv6, int32_t* mat
 }
 
 int pt_get_material(PtContext* c, int index, PtMaterial* out) {
+    PT_TRY
     if (!c || !out || index < 0 || index >= (int)c->mesh.materials.size()) return fail(c, PT_ERR_INVALID_ARG, "pt_get_material: bad index");
     to_public(c->mesh.materials[index], out);
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_get_texture(PtContext* c, int material, uint8_t* rgb) {
@@ -984,6 +1034,7 @@ int pt_get_env(PtContext* c, float* rgb, int* w, int* h) {
 
 // ---- accelerator ----
 int pt_build(PtContext* c, int accel) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     if (accel != PT_ACCEL_BVH && accel != PT_ACCEL_KD) return fail(c, PT_ERR_INVALID_ARG, "unknown accelerator kind");
     if (c->mesh.num_tris() == 0) return fail(c, PT_ERR_NOT_READY, "no mesh loaded");
@@ -1000,6 +1051,7 @@ int pt_build(PtContext* c, int accel) {
     if (rc != PT_OK) return rc;
     c->built = true;
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_get_tree(PtContext* c, int* n_nodes, int* n_refs, int* max_depth, int32_t* left, int32_t* right, int32_t* first,
@@ -1054,15 +1106,19 @@ int pt_reset(PtContext* c) {
 
 // ---- hot path ----
 int pt_render(PtContext* c, int spp) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     int rc = render_range(c, spp, 0, spp);
     if (rc != PT_OK) return rc;
     return pt_resolve(c);
+    PT_CATCH(c)
 }
 
 int pt_render_split(PtContext* c, int spp_frame, int first, int count) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     return render_range(c, spp_frame, first, count);
+    PT_CATCH(c)
 }
 
 int pt_resolve(PtContext* c) {
@@ -1078,12 +1134,15 @@ int pt_resolve(PtContext* c) {
 int pt_total_samples(PtContext* c) { return c ? c->total_samples : PT_ERR_INVALID_ARG; }
 
 int pt_synchronize(PtContext* c) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     return settle(c);
+    PT_CATCH(c)
 }
 
 int pt_download(PtContext* c, int which, float* dst) {
+    PT_TRY
     if (!c || !dst) return PT_ERR_INVALID_ARG;
     if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
     int rc = pt_synchronize(c);
@@ -1091,6 +1150,7 @@ int pt_download(PtContext* c, int which, float* dst) {
     const size_t n = (size_t)c->width * c->height * 3;
     PT_HIP(c, hipMemcpy(dst, which == 0 ? c->accum_ptr() : c->d_frame.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
+    PT_CATCH(c)
 }
 
 void* pt_accum_device_ptr(PtContext* c) { return c ? (void*)c->accum_ptr() : nullptr; }
@@ -1104,6 +1164,7 @@ int pt_use_external_accum(PtContext* c, void* device_ptr) {
 }
 
 static int save_image(PtContext* c, int which, const char* path, bool png) {
+    PT_TRY
     if (!c || !path) return PT_ERR_INVALID_ARG;
     std::vector<float> img((size_t)c->width * c->height * 3);
     int rc = pt_download(c, which, img.data());
@@ -1117,6 +1178,7 @@ static int save_image(PtContext* c, int which, const char* path, bool png) {
         return fail(c, PT_ERR_IO, err);
     }
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_save_png(PtContext* c, int which, const char* path) { return save_image(c, which, path, true); }
@@ -1124,14 +1186,17 @@ int pt_save_pfm(PtContext* c, int which, const char* path) { return save_image(c
 
 // ---- recording ----
 int pt_record_begin(PtContext* c, const char* path, int delay_cs) {
+    PT_TRY
     if (!c || !path || delay_cs < 0 || delay_cs > 65535) return PT_ERR_INVALID_ARG;
     if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
     std::string err;
     if (!c->recording.begin(path, c->width, c->height, delay_cs, err)) return fail(c, PT_ERR_IO, err);
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_record_frame(PtContext* c) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     if (!c->recording.open()) return fail(c, PT_ERR_NOT_READY, "pt_record_begin has not been called");
     if (c->recording.width() != c->width || c->recording.height() != c->height)
@@ -1144,6 +1209,7 @@ int pt_record_frame(PtContext* c) {
     std::string err;
     if (!c->recording.frame(q.data(), err)) return fail(c, PT_ERR_IO, err);
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_record_end(PtContext* c) {
@@ -1153,6 +1219,7 @@ int pt_record_end(PtContext* c) {
 }
 
 int pt_encode_gif(const char* path, const uint8_t* rgb8, int n_frames, int width, int height, int delay_cs) {
+    PT_TRY
     if (!path || !rgb8 || n_frames < 0 || delay_cs < 0 || delay_cs > 65535) return PT_ERR_INVALID_ARG;
     GifWriter g;
     std::string err;
@@ -1161,44 +1228,45 @@ int pt_encode_gif(const char* path, const uint8_t* rgb8, int n_frames, int width
         if (!g.frame(rgb8 + (size_t)f * width * height * 3, err)) return PT_ERR_IO;
     g.end();
     return PT_OK;
+    PT_CATCH((PtContext*)nullptr)
 }
 
 // ---- parity entry ----
 int pt_trace_batch(PtContext* c, int n, const float* rays6, int32_t* tri, float* t, float* bary2) {
+    PT_TRY
     if (!c || n < 0 || (n > 0 && (!rays6 || !tri || !t))) return fail(c, PT_ERR_INVALID_ARG, "pt_trace_batch: bad arguments");
     if (!c->built) return fail(c, PT_ERR_NOT_READY, "pt_build has not been called");
     if (n == 0) return PT_OK;
     PT_HIP(c, hipSetDevice(c->device));
-    DeviceBuffer<float> d_rays, d_t, d_bary;
-    DeviceBuffer<int> d_tri;
-    DeviceBuffer<float4> d_o, d_d, d_h;
-    int rc = PT_OK;
+    DeviceBuffer<float>&d_rays = c->tb_rays, &d_t = c->tb_t, &d_bary = c->tb_bary;
+    DeviceBuffer<int>& d_tri = c->tb_tri;
+    DeviceBuffer<float4>&d_o = c->tb_o, &d_d = c->tb_d, &d_h = c->tb_h;
     auto body = [&]() -> int {
-        PT_HIP(c, d_rays.upload(rays6, 6 * (size_t)n, c->stream));
-        PT_HIP(c, d_o.ensure(n)); PT_HIP(c, d_d.ensure(n)); PT_HIP(c, d_h.ensure(n));
-        PT_HIP(c, d_tri.ensure(n)); PT_HIP(c, d_t.ensure(n)); PT_HIP(c, d_bary.ensure(2 * (size_t)n));
-        const LaunchCfg cfg = cfg_of(c);
-        PT_HIP(c, launch_pack_rays(cfg, d_rays.ptr, n, d_o.ptr, d_d.ptr));
-        int nb = (n + 255) / 256;
-        nb = nb > c->blocks ? c->blocks : nb;
-        const int cap_block = (n + nb - 1) / nb;
-        {
-            ScopedTimer tm(c, PT_TIMER_TRACE);
-            PT_HIP(c, launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, d_o.ptr, d_d.ptr, d_h.ptr,
-                                   nullptr, n, nb, cap_block, c->d_block_stats.ptr));
-        }
-        c->batch_rays += (uint64_t)n;
-        PT_HIP(c, launch_unpack_hits(cfg, d_h.ptr, n, d_tri.ptr, d_t.ptr, d_bary.ptr));
-        PT_HIP(c, hipMemcpyAsync(tri, d_tri.ptr, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        PT_HIP(c, hipMemcpyAsync(t, d_t.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        if (bary2) PT_HIP(c, hipMemcpyAsync(bary2, d_bary.ptr, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        PT_HIP(c, hipStreamSynchronize(c->stream));
-        return PT_OK;
+    PT_HIP(c, d_rays.upload(rays6, 6 * (size_t)n, c->stream));
+    PT_HIP(c, d_o.ensure(n)); PT_HIP(c, d_d.ensure(n)); PT_HIP(c, d_h.ensure(n));
+    PT_HIP(c, d_tri.ensure(n)); PT_HIP(c, d_t.ensure(n)); PT_HIP(c, d_bary.ensure(2 * (size_t)n));
+    const LaunchCfg cfg = cfg_of(c);
+    PT_HIP(c, launch_pack_rays(cfg, d_rays.ptr, n, d_o.ptr, d_d.ptr));
+    int nb = (n + 255) / 256;
+    nb = nb > c->blocks ? c->blocks : nb;
+    const int cap_block = (n + nb - 1) / nb;
+    {
+        ScopedTimer tm(c, PT_TIMER_TRACE);
+        PT_HIP(c, launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, d_o.ptr, d_d.ptr, d_h.ptr,
+                               nullptr, n, nb, cap_block, c->d_block_stats.ptr));
+    }
+    c->batch_rays += (uint64_t)n;
+    PT_HIP(c, launch_unpack_hits(cfg, d_h.ptr, n, d_tri.ptr, d_t.ptr, d_bary.ptr));
+    PT_HIP(c, hipMemcpyAsync(tri, d_tri.ptr, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipMemcpyAsync(t, d_t.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (bary2) PT_HIP(c, hipMemcpyAsync(bary2, d_bary.ptr, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    return PT_OK;
     };
-    rc = body();
-    (void)hipStreamSynchronize(c->stream);
-    d_rays.release(); d_t.release(); d_bary.release(); d_tri.release(); d_o.release(); d_d.release(); d_h.release();
+    const int rc = body();
+    // nothing of the call may still be writing into the caller's arrays when it returns, whatever the outcome
+    if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PT_OK) return fail(c, PT_ERR_HIP, "pt_trace_batch: stream synchronisation failed");
     return rc;
+    PT_CATCH(c)
 }
 
 int pt_camera_rays(PtContext* c, float* rays6) {
@@ -1224,6 +1292,7 @@ int pt_camera_rays(PtContext* c, float* rays6) {
 
 // ---- measurement ----
 int pt_get_counters(PtContext* c, uint64_t out[PT_CNT_COUNT]) {
+    PT_TRY
     if (!c || !out) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     int rc = pt_synchronize(c);
@@ -1246,9 +1315,11 @@ int pt_get_counters(PtContext* c, uint64_t out[PT_CNT_COUNT]) {
     out[PT_CNT_REPAIRED] = c->repaired_batches;
     out[PT_CNT_TAIL_RAYS] = d[DC_TAIL_RAYS];
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_reset_counters(PtContext* c) {
+    PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     int rc0 = settle(c);
@@ -1261,6 +1332,7 @@ int pt_reset_counters(PtContext* c) {
     c->batch_rays = 0;
     for (int i = 0; i < PT_TIMER_COUNT; i++) { c->timer_ms[i] = 0; c->timer_launches[i] = 0; }
     return PT_OK;
+    PT_CATCH(c)
 }
 
 int pt_get_timers(PtContext* c, double ms[PT_TIMER_COUNT], uint64_t launches[PT_TIMER_COUNT]) {

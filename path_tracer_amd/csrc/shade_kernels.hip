@@ -118,9 +118,12 @@ __global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float
 
 // Per level (one workgroup each): total queue population of the batch = closest-hit queries of
 // that level; the sum over levels goes to DC_RAYS, the largest level to DC_MAXQ.
+// A batch whose overflow flag is set added nothing to the image and is rendered again in pieces,
+// which are tallied themselves; it is left out here as in accumulate_kernel.
 __global__ __launch_bounds__(256) void tally_kernel(const int* __restrict__ qcount, int blocks, int tail_level,
-                                                    unsigned long long* __restrict__ totals) {
+                                                    const int* __restrict__ overflow, unsigned long long* __restrict__ totals) {
     __shared__ unsigned long long s_sum[256];
+    if (*overflow) return;
     const int level = blockIdx.x;
     unsigned long long part = 0;
     for (int k = threadIdx.x; k < blocks; k += blockDim.x) part += (unsigned long long)qcount[(size_t)level * blocks + k];
@@ -193,8 +196,9 @@ hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const 
     return hipGetLastError();
 }
 
-hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, int tail_level, unsigned long long* totals) {
-    hipLaunchKernelGGL(tally_kernel, dim3(levels), dim3(256), 0, cfg.stream, qcount, blocks, tail_level, totals);
+hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, int tail_level, const int* overflow,
+                        unsigned long long* totals) {
+    hipLaunchKernelGGL(tally_kernel, dim3(levels), dim3(256), 0, cfg.stream, qcount, blocks, tail_level, overflow, totals);
     return hipGetLastError();
 }
 

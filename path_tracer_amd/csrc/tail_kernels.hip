@@ -78,7 +78,8 @@ hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchG
     const bool recip = (mode & 1) != 0;
     // the refill threshold rides above leave_k; unset, a scene walked entirely in LDS waits for half a wave
     // (short walks: fuller refills pay), any other for eight lanes (long walks: idle lanes cost more)
-    const int refill = (mode >> 8) & 127 ? (mode >> 8) & 127 : (fits_lds(scene) ? 32 : 8);
+    const int asked = (mode >> 8) & 127;
+    const int refill = asked ? (asked > 64 ? 64 : asked) : (fits_lds(scene) ? 32 : 8);  // a wave never has more than 64 idle lanes
     // node-phase leave rule: 0 = per scene (4 in LDS, else 1), 15 = stay until nobody walks
     const int k_bits = (mode >> 4) & 15;
     const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 0 : k_bits);

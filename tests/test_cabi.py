@@ -63,3 +63,18 @@ def test_python_constants_equal_the_header_enums():
     assert L.pt_get_option(h, pta.OPT_STREAMS, ctypes.byref(v)) == pta.PT_OK and v.value == 2
     assert L.pt_set_option(h, pta.OPT_STREAMS, ctypes.c_uint64(5)) == pta.ERR_INVALID_ARG
     L.pt_destroy(h)
+
+
+def test_refill_threshold_above_a_wave_is_refused():
+    """Bits 8..14 of PT_OPT_TRAVERSAL are the idle lanes a wave waits for before it fetches rays; a
+    wave has 64, so a larger value could never be met and the walk would not end."""
+    L = pta.lib()
+    h = ctypes.c_void_p()
+    v = ctypes.c_uint64()
+    assert L.pt_create(pta.DEVICE_NONE, ctypes.byref(h)) == pta.PT_OK
+    assert L.pt_set_option(h, pta.OPT_TRAVERSAL, ctypes.c_uint64(0x4041)) == pta.PT_OK   # 64: a whole wave idle
+    assert L.pt_set_option(h, pta.OPT_TRAVERSAL, ctypes.c_uint64(0x4141)) == pta.ERR_INVALID_ARG  # 65
+    assert L.pt_set_option(h, pta.OPT_TRAVERSAL, ctypes.c_uint64(0x7F01)) == pta.ERR_INVALID_ARG  # 127
+    assert L.pt_set_option(h, pta.OPT_TRAVERSAL, ctypes.c_uint64(0x10001)) == pta.ERR_INVALID_ARG  # unknown bit
+    assert L.pt_get_option(h, pta.OPT_TRAVERSAL, ctypes.byref(v)) == pta.PT_OK and v.value == 0x4041
+    L.pt_destroy(h)
