@@ -89,6 +89,9 @@ enum {
                                  negative indices, face lines of any length.  Default 0 = the reference's behaviour */
     PT_OPT_BLOCKS_PER_CU = 12,/* workgroups (queue regions) per compute unit a batch is split over, 1..8; 0 = chosen per
                                  scene so that one launch of the trace kernel is resident at once */
+    PT_OPT_TREE_IN_LDS = 14,  /* read only: 1 when the built scene's whole tree and its intersection records are staged in LDS by
+                                 the trace kernels (small scenes: the walk then has no global-memory path, so instruction
+                                 issue and not memory bandwidth bounds it) */
     PT_OPT_STREAMS = 13       /* batches in flight, 1..4 (default 2).  Consecutive batches (frames, when a frame is one
                                  batch) run on internal streams with queues of their own, so the thinly populated late
                                  levels of one overlap the early levels of the next; the kernels that touch the image
@@ -226,6 +229,16 @@ int pt_encode_gif(const char* path, const uint8_t* rgb8, int n_frames, int width
  * mesh order or -1; t: hit distance or FLT_MAX; bary2 (optional): the beta, gamma of
  * src/cs488.h:661-662. */
 int pt_trace_batch(PtContext* ctx, int n, const float* rays6, int32_t* tri, float* t, float* bary2);
+/* pt_trace_batch for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  All four arrays are DEVICE memory of the
+ * context's GPU (d_bary2 may be NULL); the call only queues kernels on the context's stream and returns, so the
+ * results are ready once that stream has been waited for (pt_synchronize, or the caller's own stream given to
+ * pt_set_stream).  Neither this call nor anything it calls allocates or frees: the packed rays and the hit records
+ * are staged in a file-scope device array of 6 MiB that every GPU the library runs on holds until the process
+ * ends.  Limits: n <= PT_TRACE_STATIC_MAX_RAYS, otherwise PT_ERR_INVALID_ARG.  All contexts on one GPU share
+ * that GPU's array: two such calls that overlap on one GPU (different streams or threads) race. */
+#define PT_TRACE_STATIC_MAX_RAYS (1 << 17)
+int pt_trace_batch_static(PtContext* ctx, int n, const float* d_rays6, int32_t* d_tri, float* d_t, float* d_bary2);
 /* The reference's camera rays for the current camera and resolution, pixel-centre form
  * (src/cs488.h:1780-1794), n = W*H rays in pixel order; for tests of the camera model. */
 int pt_camera_rays(PtContext* ctx, float* rays6);

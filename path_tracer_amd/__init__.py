@@ -22,13 +22,14 @@ ERR_INVALID_ARG, ERR_IO, ERR_INVALID_OBJ, ERR_NOT_READY, ERR_HIP, ERR_QUEUE_OVER
     -1, -2, -3, -4, -5, -6, -7, -8)
 ERR_NO_MEMORY, ERR_RCCL = -9, -10
 
-OPT_SEED, OPT_MAX_LEVEL, OPT_COUNT_TESTS, OPT_PROFILE, OPT_MAX_BATCH, OPT_QUEUE_FACTOR, OPT_LDS_NODES, OPT_TRAVERSAL, OPT_TAIL_LEVEL, OPT_BUILD_THREADS, OPT_OBJ_EXTENDED, OPT_BLOCKS_PER_CU, OPT_STREAMS = (
-    range(1, 14))
+OPT_SEED, OPT_MAX_LEVEL, OPT_COUNT_TESTS, OPT_PROFILE, OPT_MAX_BATCH, OPT_QUEUE_FACTOR, OPT_LDS_NODES, OPT_TRAVERSAL, OPT_TAIL_LEVEL, OPT_BUILD_THREADS, OPT_OBJ_EXTENDED, OPT_BLOCKS_PER_CU, OPT_STREAMS, OPT_TREE_IN_LDS = (
+    range(1, 15))
 CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SAMPLES, CNT_NAN_SAMPLES, CNT_HITS, CNT_MAX_QUEUE, CNT_REPAIRED, CNT_TAIL_RAYS = range(9)
 CNT_WAVE_STEPS, CNT_WAVE_ROUNDS, CNT_STREAM_SWAPS = 9, 10, 11
 CNT_COUNT = 12
 TIMER_RAYGEN, TIMER_TRACE, TIMER_SHADE, TIMER_ACCUM, TIMER_TAIL = range(5)
 TIMER_COUNT = 5
+TRACE_STATIC_MAX_RAYS = 1 << 17
 
 # every symbol include/pt_amd.h declares
 EXPORTS = [
@@ -38,7 +39,7 @@ EXPORTS = [
     "pt_get_env", "pt_build", "pt_get_tree", "pt_set_camera", "pt_set_resolution", "pt_reset", "pt_render",
     "pt_render_split", "pt_resolve", "pt_total_samples", "pt_synchronize", "pt_download", "pt_accum_device_ptr",
     "pt_use_external_accum", "pt_save_png", "pt_save_pfm", "pt_trace_batch", "pt_camera_rays", "pt_get_counters",
-    "pt_reset_counters", "pt_get_timers", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
+    "pt_reset_counters", "pt_get_timers", "pt_trace_batch_static", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
 ]
 
 
@@ -309,6 +310,12 @@ class Scene:
         bary = np.zeros((n, 2), np.float32)
         self._check(self.L.pt_trace_batch(self.h, n, _fp(rays), _ip(tri), _fp(t), _fp(bary)))
         return dict(tri=tri, t=t, bary=bary)
+
+    def intersect_static(self, d_rays, d_tri, d_t, d_bary=None, n=None):
+        """pt_trace_batch_static: device addresses (ints) of n x 6 float rays and of the outputs; asynchronous
+        on the context's stream and free of allocations."""
+        self._check(self.L.pt_trace_batch_static(self.h, int(n), C.c_void_p(d_rays), C.c_void_p(d_tri), C.c_void_p(d_t),
+                                                 C.c_void_p(d_bary) if d_bary else None))
 
     def camera_rays(self):
         rays = np.zeros((self.width * self.height, 6), np.float32)

@@ -131,6 +131,8 @@ hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const Batch
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
                         int* qcount_out);
 int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode);
+// 1 when the trace kernels stage the scene's whole tree and all intersection records in LDS
+int trace_scene_in_lds(const SceneGpu& scene);
 hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int kd, int mode, int level0, int levels,
                        int max_level, QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount,
                        unsigned long long* block_stats);
@@ -146,6 +148,11 @@ hipError_t launch_clear(const LaunchCfg& cfg, float* buf, size_t n);
 hipError_t launch_spin(const LaunchCfg& cfg, int microseconds);
 // unpacks rays6 (n x 6 floats) into queue form for the batch-trace entry
 hipError_t launch_pack_rays(const LaunchCfg& cfg, const float* rays6, int n, float4* ray_o, float4* ray_d);
+// Most rays of one pt_trace_batch_static call: its staging lives in a file-scope device array of
+// 3 float4 per ray (6 MiB per GPU).
+enum { TRACE_STATIC_MAX_RAYS = 1 << 17 };
+// device address of that array on `device` (the current device); cached per device
+hipError_t trace_static_scratch(int device, float4** out);
 hipError_t launch_unpack_hits(const LaunchCfg& cfg, const float4* hit, int n, int* tri, float* t, float* bary2);
 
 }  // namespace pt

@@ -149,6 +149,8 @@ struct PtContext {
     DeviceBuffer<int> tb_tri;
     DeviceBuffer<float4> tb_o, tb_d, tb_h;
 
+    float4* static_scratch = nullptr;  // this device's copy of the file-scope staging array of pt_trace_batch_static
+
     GifWriter recording;
 
     // measurement
@@ -797,6 +799,10 @@ int pt_create(int device, PtContext** out) {
         return PT_ERR_HIP;
     }
     (void)hipStreamSynchronize(nullptr);  // the clears above, before any stream of the context is used
+    if (trace_static_scratch(device, &c->static_scratch) != hipSuccess) {  // the device is current here
+        pt_destroy(c);
+        return PT_ERR_HIP;
+    }
     *out = c;
     return PT_OK;
 }
@@ -905,6 +911,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
         case PT_OPT_BUILD_THREADS: *value = (uint64_t)c->build_threads; break;
         case PT_OPT_OBJ_EXTENDED: *value = (uint64_t)c->obj_extended; break;
         case PT_OPT_BLOCKS_PER_CU: *value = (uint64_t)c->blocks_per_cu; break;
+        case PT_OPT_TREE_IN_LDS: *value = c->built && c->device != PT_DEVICE_NONE ? (uint64_t)trace_scene_in_lds(c->scene) : 0; break;
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
     return PT_OK;
@@ -1267,6 +1274,33 @@ int pt_trace_batch(PtContext* c, int n, const float* rays6, int32_t* tri, float*
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == PT_OK) return fail(c, PT_ERR_HIP, "pt_trace_batch: stream synchronisation failed");
     return rc;
     PT_CATCH(c)
+}
+
+// The same closest-hit query on device-resident arrays, without any allocation: the packed rays and
+// the hit records are staged in this GPU's copy of a file-scope device array.
+int pt_trace_batch_static(PtContext* c, int n, const float* d_rays6, int32_t* d_tri, float* d_t, float* d_bary2) {
+    if (!c || n < 0 || (n > 0 && (!d_rays6 || !d_tri || !d_t))) return fail_noexcept(c, PT_ERR_INVALID_ARG, "pt_trace_batch_static: bad arguments");
+    if (c->device == PT_DEVICE_NONE || !c->built) return fail_noexcept(c, PT_ERR_NOT_READY, "pt_build has not been called");
+    if (n > TRACE_STATIC_MAX_RAYS) return fail_noexcept(c, PT_ERR_INVALID_ARG, "pt_trace_batch_static: more than 131072 rays in one call (the static staging array holds no more)");
+    if (n == 0) return PT_OK;
+    if (!c->static_scratch) return fail_noexcept(c, PT_ERR_HIP, "pt_trace_batch_static: the staging array's device address is unknown");
+    if (hipSetDevice(c->device) != hipSuccess) return fail_noexcept(c, PT_ERR_HIP, "pt_trace_batch_static: hipSetDevice failed");
+    float4* const ray_o = c->static_scratch;
+    float4* const ray_d = ray_o + TRACE_STATIC_MAX_RAYS;
+    float4* const hits = ray_d + TRACE_STATIC_MAX_RAYS;
+    const LaunchCfg cfg = cfg_of(c);
+    // every entry a kernel of this call reads is written by the call first (pack -> trace -> unpack), so what
+    // the previous call left in the array needs no clearing
+    if (launch_pack_rays(cfg, d_rays6, n, ray_o, ray_d) != hipSuccess) return fail_noexcept(c, PT_ERR_HIP, "pt_trace_batch_static: launch failed");
+    int nb = (n + 255) / 256;
+    nb = nb > c->blocks ? c->blocks : nb;
+    const int cap_block = (n + nb - 1) / nb;
+    if (launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, ray_o, ray_d, hits, nullptr, n, nb, cap_block,
+                     c->d_block_stats.ptr) != hipSuccess)
+        return fail_noexcept(c, PT_ERR_HIP, "pt_trace_batch_static: launch failed");
+    c->batch_rays += (uint64_t)n;
+    if (launch_unpack_hits(cfg, hits, n, d_tri, d_t, d_bary2) != hipSuccess) return fail_noexcept(c, PT_ERR_HIP, "pt_trace_batch_static: launch failed");
+    return PT_OK;
 }
 
 int pt_camera_rays(PtContext* c, float* rays6) {

@@ -2,11 +2,24 @@
 // launchers (gfx950).  The walk itself is in trace_device.h.
 #include "trace_device.h"
 
+#include <mutex>
+
+// Scratch of pt_trace_batch_static (the entry point that allocates nothing): room for the packed
+// origins, the packed directions and the hit records of TRACE_STATIC_MAX_RAYS rays, 6 MiB per GPU,
+// held until the process ends.  In host code the array's name is not a device address: the address
+// on a device comes from hipGetSymbolAddress with that device current (trace_static_scratch below),
+// and only that pointer is handed to kernels.
+static __device__ __align__(256) float4 scratch[3 * pt::TRACE_STATIC_MAX_RAYS];
+
 namespace pt {
 
 namespace {
 
 using namespace trace_dev;
+
+enum { SCRATCH_DEVICES = 64 };
+float4* g_scratch_ptr[SCRATCH_DEVICES] = {};  // per device: each GPU holds its own copy at its own address
+std::mutex g_scratch_mutex;
 
 // One 256-lane workgroup per queue region; the region's length is read from device memory
 // (written by the previous stage), so the host never waits for a count.
@@ -129,6 +142,24 @@ int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode) {
     int n = kd ? (recip ? resident_of<true, SLAB_RECIP>(scene) : resident_of<true, SLAB_DIVIDE>(scene))
                : (recip ? resident_of<false, SLAB_RECIP>(scene) : resident_of<false, SLAB_DIVIDE>(scene));
     return n < 1 ? 8 : (n > 8 ? 8 : n);
+}
+
+int trace_scene_in_lds(const SceneGpu& scene) { return fits_lds(scene) ? 1 : 0; }
+
+// Device address of `scratch` on `device`, which must be the current device.  Looked up once per
+// device (pt_create does it, so the entry point itself only reads the table).
+hipError_t trace_static_scratch(int device, float4** out) {
+    *out = nullptr;
+    if (device < 0 || device >= SCRATCH_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = static_cast<float4*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
 }
 
 hipError_t launch_pack_rays(const LaunchCfg& cfg, const float* rays6, int n, float4* ray_o, float4* ray_d) {

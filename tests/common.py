@@ -116,3 +116,36 @@ def ray_batch(pos, n_random=2000, n_vertex=300, seed=3, eye=(0.0, 0.0, 1.5)):
 
 def rmse(a, b):
     return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+class DeviceArray:
+    """A device allocation of the HIP runtime the library itself uses (no PyTorch: its own copy of the
+    runtime cannot open the GPU once the system one has), for tests that hand device pointers to the C ABI."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes
+            import path_tracer_amd as pta
+            pta.lib()  # loads libamdhip64 as a dependency; the name below then resolves to that same copy
+            cls._hip = ctypes.CDLL("libamdhip64.so")
+        return cls._hip
+
+    def __init__(self, array):
+        import ctypes
+        self.host = np.ascontiguousarray(array)
+        self.ptr = ctypes.c_void_p()
+        assert self.hip().hipMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(max(self.host.nbytes, 4))) == 0
+        assert self.hip().hipMemcpy(self.ptr, self.host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(self.host.nbytes), 1) == 0
+
+    def download(self):
+        import ctypes
+        out = np.empty_like(self.host)
+        assert self.hip().hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), self.ptr, ctypes.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip().hipFree(self.ptr)
+            self.ptr = None
