@@ -11,9 +11,19 @@ With N > 1 (one process per GPU, launched by torch.distributed.run) every rank r
 per-frame accumulation buffers are summed onto rank 0 with one RCCL reduce.
 
 Prints one JSON line on rank 0: metric / value (closest-hit queries per second, whole job), spp_per_s,
-ms_per_step, `roofline` for the dominant kernel (algorithmic bytes per launch over the launch time measured
-with HIP events, committed counter figures for HBM traffic and VALU use), per-stage milliseconds, a short
-kd-tree run, and `cpu_baseline` (the CPU oracle timed on this host, rank 0 at N = 1 only).
+ms_per_step, `roofline` for the dominant kernel, per-stage milliseconds, a short kd-tree run, a `sponza`
+sub-record (the large-tree regime: 210 k-triangle stand-in at 3840x2160, both accelerators) and `cpu_baseline`
+(the CPU oracle timed on this host, rank 0 at N = 1 only).
+
+Which ceiling `roofline` is quoted against follows from where the walk's operands come from.  A scene whose
+whole tree is staged in LDS (PT_OPT_TREE_IN_LDS: the Cornell boxes) has no global-memory path in the walk:
+its node and triangle operands cost instruction issue, not bandwidth, so the bound is the FP32 vector peak and
+`achieved` = algorithmic FLOPs (27 per slab test + 75 per triangle test, both counted by the kernel itself in
+an untimed pass) per launch / the launch time measured live with HIP events.  For a tree that leaves the CU the
+same FP32 fraction is reported beside the measured byte rates at L2 and HBM, and `bound` names the ceiling the
+kernel is closest to.  HBM bytes per launch (`traffic`) come from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+passes run by this program on the same workload before it opens the GPU itself (`traffic_source` says so), or,
+when the profiler cannot be run, from the committed passes under profiles/.
 """
 import argparse
 import json
@@ -28,7 +38,12 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E, spec
+L1_PEAK_GBS = 256 * 64 * 2.4 # vector L1: one 64-byte access per clock and CU, 256 CUs, 2.4 GHz = 39.3 TB/s
+L2_PEAK_GBS = 34500.0       # aggregate over the eight XCDs' L2 caches, measured figure of the hardware guide
+FP32_PEAK_TFLOPS = 157.3    # 256 CUs x 4 SIMDs x 64 FMA lanes per 2 cycles x 2 FLOP x 2.4 GHz
+FLOP_PER_BOX_TEST = 27.0    # 6 subtractions + 6 divisions + 3 swaps + 4 min/max + 2 sign tests + entry compare, as counted for the reference's slab test
+FLOP_PER_TRI_TEST = 75.0    # two cross products, four dot products, three divisions, the barycentric and range tests
 
 WORKLOADS = {
     # name: (obj, needs probe)
@@ -77,34 +92,74 @@ def workload_camera(args):
     return None
 
 
-def measured_traffic(args, world):
-    """HBM bytes per trace_kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs of the same workload, read side doubled as gfx950 needs);
-    counters cannot be read inside this process, so the number is only attached to the workload
-    those passes ran (the default one) and is null otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    is_default = (args.workload == "cornellbox" and not args.obj and args.accel == "bvh" and
-                  (args.width, args.height, args.spp) == (1024, 1024, 10) and world == 1)
-    if not is_default or not os.path.exists(path):
-        return None, None
-    k = json.load(open(path))["kernels"].get("trace_kernel")
-    return (k["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json") if k else (None, None)
+def is_default_workload(args, world):
+    return (args.workload == "cornellbox" and not args.obj and args.accel == "bvh" and
+            (args.width, args.height, args.spp) == (1024, 1024, 10) and world == 1)
 
 
-def measured_valu(args, world):
-    """VALU side of trace_kernel from the committed SQ counter passes (tools/pmc_valu.py): share of
-    the chip's VALU issue slots in use and lanes active per VALU instruction.  Same restriction as
-    measured_traffic: only for the workload the passes ran."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_valu.json")
-    is_default = (args.workload == "cornellbox" and not args.obj and args.accel == "bvh" and
-                  (args.width, args.height, args.spp) == (1024, 1024, 10) and world == 1)
-    if not is_default or not os.path.exists(path):
+def committed_counters(args, world):
+    """Counter figures of trace_kernel from the committed rocprofv3 --pmc passes (profiles/r02_pmc_*.json:
+    tools/gpu_pmc_all.sh on the same workload, one frame in flight).  Only attached to the workloads those
+    passes ran; None otherwise."""
+    tag = None
+    if is_default_workload(args, world):
+        tag = "cornellbox_bvh"
+    elif args.workload == "sponza" and not args.obj and (args.width, args.height, args.spp) == (3840, 2160, 4) and world == 1:
+        tag = "sponza_%s" % args.accel
+    if tag is None:
         return None
-    k = json.load(open(path))["kernels"].get("trace_kernel")
-    if not k:
+    out = {}
+    for kind in ("valu", "cache"):
+        path = os.path.join(ROOT, "profiles", "r02_pmc_%s_%s.json" % (kind, tag))
+        if os.path.exists(path):
+            k = json.load(open(path))["kernels"].get("trace_kernel")
+            if k:
+                out[kind] = k
+                out[kind + "_source"] = "profiles/r02_pmc_%s_%s.json" % (kind, tag)
+    return out or None
+
+
+def live_hbm_traffic(args, world):
+    """HBM bytes per trace_kernel launch measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; a pass
+    cannot hold both) over three frames of the default workload in child processes, run BEFORE this process opens
+    the GPU.  Returns (bytes per launch, launches seen) or None when the profiler is absent, this program is itself
+    being profiled, or a pass fails; never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not is_default_workload(args, world) or args.no_pmc or shutil.which("rocprofv3") is None:
         return None
-    return {"issue_busy": k.get("valu_issue_busy"), "salu_issue_busy": k.get("salu_issue_busy"), "lane_occupancy": k.get("valu_lane_occupancy"),
-            "wave_instructions_per_launch": k["per_launch"].get("SQ_INSTS_VALU"), "source": "profiles/r01_pmc_valu.json"}
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ):
+        return None  # already under a profiler: a nested one would fight over the counters
+    tmp = tempfile.mkdtemp(prefix="pt_bench_pmc_")
+    env = dict(os.environ, TMPDIR=tmp)
+    tot = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["timeout", "-s", "KILL", "90", "rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "prof_frame.py"), "cornellbox.obj", "1024", "3", "bvh"]
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+            if r.returncode != 0:
+                return None
+            kib, ids = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and "trace_kernel" in row["Kernel_Name"]:
+                        kib += float(row["Counter_Value"])
+                        ids.add(row["Dispatch_Id"])
+            if not ids:
+                return None
+            tot[counter] = (kib * 1024.0, len(ids))
+        # gfx950 tallies the 128-byte requests of a wide coalesced read as 64 bytes: the read side is doubled
+        launches = tot["FETCH_SIZE"][1]
+        return (tot["FETCH_SIZE"][0] * 2.0 / launches + tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1], launches)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def bytes_per_ray(n_box, n_tri, hit_frac, textured=False):
@@ -156,13 +211,21 @@ def probe_path(args):
 
 
 def cpu_baseline(args):
-    """The CPU restatement of the reference's multithreaded loop (column strips, one thread per
-    strip), timed on this host on a bounded sample of the same workload."""
+    """The CPU restatement of the reference's multithreaded loop (column strips, one thread per strip), timed on
+    this host on a bounded sample of the same workload: once with one thread per core this process may run on, and
+    once under the reference's own rule of 3 x hardware_concurrency threads (src/cs488.h:98)."""
     import orc
     from PIL import Image
     from common import read_hdr_independent
     needs_probe = WORKLOADS[args.workload][1]
-    cores = min(16, os.cpu_count() or 1)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    # a GPU box hands a job a share of its CPUs through OMP_NUM_THREADS-style limits rather than through the
+    # affinity mask; never start more worker threads than that share
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    cores = max(1, min(usable, share) if share > 0 else min(usable, 16))
     o = orc.Oracle()
     if o.load_obj(workload_obj(args)) <= 0:
         raise SystemExit("oracle cannot load the workload")
@@ -180,23 +243,122 @@ def cpu_baseline(args):
     while (w // shrink) * (h // shrink) * args.spp > 12_000_000:
         shrink *= 2
     w, h = w // shrink, h // shrink
-    o.reset(w, h)
-    o.render(spp=1, frames=1, threads=cores)  # warm-up
-    o.reset(w, h)
-    frames, t0, rays = 0, time.time(), 0
-    while True:
-        _, _, cnt = o.render(spp=args.spp, frames=1, threads=cores)
-        rays += int(cnt[0])
-        frames += 1
-        dt = time.time() - t0
-        if dt > 10.0 or frames >= 5:
-            break
+
+    def timed(threads, budget_s, most_frames):
+        o.reset(w, h)
+        o.render(spp=1, frames=1, threads=threads)  # warm-up
+        o.reset(w, h)
+        frames, t0, rays = 0, time.time(), 0
+        while True:
+            _, _, cnt = o.render(spp=args.spp, frames=1, threads=threads)
+            rays += int(cnt[0])
+            frames += 1
+            dt = time.time() - t0
+            if dt > budget_s or frames >= most_frames:
+                return rays / dt * 1e-6, frames, dt
+
+    mrays, frames, dt = timed(cores, 10.0, 5)
+    hw = os.cpu_count() or 1
+    ref_threads = min(3 * hw, w)  # src/cs488.h:98; a strip narrower than one column holds no pixel (src/cs488.h:1885-1890)
+    ref_mrays, ref_frames, _ = timed(ref_threads, 6.0, 3)
     return {
-        "value": rays / dt * 1e-6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "value": mrays, "unit": "Mrays/s", "cores": cores, "kind": "port",
         "spp_per_s": frames * args.spp / dt * (w * h) / float(args.width * args.height),
+        "host": {"hardware_concurrency": hw, "cpus_this_process_may_use": usable, "thread_share": share or None},
+        "reference_thread_rule": {"threads": ref_threads, "value": ref_mrays, "frames": ref_frames,
+                                  "note": "numThreads = 3 x hardware_concurrency (src/cs488.h:98), capped at one thread per image column; the oracle "
+                                          "gives every strip its own PCG32 stream where the reference's threads share one state"},
         "sample": "%d frame(s) of the same view at %dx%d (1/%d of the workload's resolution per axis) x %d spp, %d threads over "
                   "column strips; spp_per_s is scaled to the workload's pixel count" % (frames, w, h, shrink, args.spp, cores),
     }
+
+
+def fp32_tflops(n_box, n_tri, rays, seconds):
+    return (FLOP_PER_BOX_TEST * n_box + FLOP_PER_TRI_TEST * n_tri) * rays / seconds * 1e-12 if seconds > 0 else 0.0
+
+
+def sponza_record(pta, args, device, stream_handle):
+    """The large-tree regime beside the default workload: the 210 k-triangle stand-in for sponza.obj (which the
+    reference does not distribute) at 3840x2160, 4 spp per frame, both accelerators.  For each: throughput over
+    a few frames, slab and triangle tests per ray from a counted pass, the FP32 fraction of trace_kernel from
+    live events (one frame in flight), and the committed cache-counter figures of the same workload."""
+    import copy
+    out = {"workload": "sponza stand-in (tools/make_sponza.py, seed 7, detail 1.0) 3840x2160, 4 spp/frame, synthetic probe"}
+    sub = copy.copy(args)
+    sub.workload, sub.obj, sub.hdr = "sponza", None, None
+    sub.width, sub.height, sub.spp = DEFAULT_SHAPE["sponza"]
+    sub.lds_nodes = sub.traversal = sub.tail_level = sub.blocks_per_cu = sub.streams = None
+    for name, accel in (("bvh", pta.BVH), ("kd", pta.KD)):
+        sub.accel = name
+        s = make_scene(pta, sub, device, accel)
+        s.set_stream(stream_handle)
+        s.set_option(pta.OPT_COUNT_TESTS, 1)
+        s.reset_counters()
+        s.pathtrace(sub.spp)
+        s.synchronize()
+        c = s.counters()
+        n_box = c[pta.CNT_BOX_TESTS] / max(c[pta.CNT_RAYS], 1)
+        n_tri = c[pta.CNT_TRI_TESTS] / max(c[pta.CNT_RAYS], 1)
+        s.set_option(pta.OPT_COUNT_TESTS, 0)
+        # trace_kernel alone: one frame in flight, events around its launches only
+        lanes = s.get_option(pta.OPT_STREAMS)
+        s.set_option(pta.OPT_STREAMS, 1)
+        s.pathtrace(sub.spp)
+        s.synchronize()
+        s.reset_counters()
+        s.set_option(pta.OPT_PROFILE, 2)
+        for _ in range(2):
+            s.pathtrace(sub.spp)
+        s.synchronize()
+        ms, launches = s.timers()
+        c = s.counters()
+        rays_kernel = float(c[pta.CNT_RAYS] - c[pta.CNT_TAIL_RAYS])
+        alone_s = ms[pta.TIMER_TRACE] * 1e-3
+        s.set_option(pta.OPT_PROFILE, 0)
+        s.set_option(pta.OPT_STREAMS, lanes)
+        # throughput as the product runs it
+        for _ in range(2):
+            s.pathtrace(sub.spp)
+        s.synchronize()
+        s.reset_counters()
+        n = 6 if name == "bvh" else 4
+        t0 = time.perf_counter()
+        for _ in range(n):
+            s.pathtrace(sub.spp)
+        s.synchronize()
+        dt = time.perf_counter() - t0
+        c = s.counters()
+        tf = fp32_tflops(n_box, n_tri, rays_kernel, alone_s)
+        rec = {"Mrays/s": c[pta.CNT_RAYS] / dt * 1e-6, "spp_per_s": n * sub.spp / dt, "ms_per_step": dt / n * 1e3, "steps": n,
+               "box_tests_per_ray": n_box, "tri_tests_per_ray": n_tri, "tree_in_lds": bool(s.get_option(pta.OPT_TREE_IN_LDS)),
+               "lds_nodes": s.get_option(pta.OPT_LDS_NODES),
+               "trace_kernel_alone": {"avg_launch_ms": ms[pta.TIMER_TRACE] / max(launches[pta.TIMER_TRACE], 1),
+                                      "rays_per_launch": rays_kernel / max(launches[pta.TIMER_TRACE], 1),
+                                      "fp32_TFLOPs": tf, "fp32_frac": tf / FP32_PEAK_TFLOPS}}
+        cc = committed_counters(sub, 1)
+        if cc:
+            rec["counters"] = summarise_counters(cc)
+        out[name] = rec
+        s.close()
+    return out
+
+
+def summarise_counters(cc):
+    """The figures of committed_counters() that the bench line carries."""
+    out = {}
+    v, c = cc.get("valu"), cc.get("cache")
+    if v:
+        out["valu_issue_busy"] = v.get("valu_issue_busy")
+        out["salu_issue_busy"] = v.get("salu_issue_busy")
+        out["valu_lane_occupancy"] = v.get("valu_lane_occupancy")
+        out["valu_source"] = cc["valu_source"]
+    if c:
+        for k in ("l1_read_hit_rate", "l1_GBs_at_64B_per_access", "l1_frac_of_peak", "l2_hit_rate", "l2_GBs_upper_bound", "l2_frac_of_peak_upper_bound", "hbm_bytes_per_launch", "hbm_GBs",
+                  "hbm_frac_of_peak", "avg_launch_s"):
+            if k in c:
+                out[k] = c[k]
+        out["cache_source"] = cc["cache_source"]
+    return out
 
 
 def main():
@@ -218,6 +380,14 @@ def main():
     ap.add_argument("--traversal", type=lambda v: int(v, 0), default=None, help="PT_OPT_TRAVERSAL bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kd", action="store_true", help="skip the short kd-tree comparison run")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --spp is the frame's TOTAL samples per pixel, split over the ranks by sample_share "
+                         "(the analogue of the reference's column strips, src/cs488.h:1885-1890); default is weak scaling, --spp per GPU")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="at N = 1 too: initialise the process group and run every frame through the sample-split entry, the "
+                         "external per-frame buffer and the reduce (a one-rank communicator), so that the path N > 1 takes executes")
+    ap.add_argument("--no-sponza", action="store_true", help="skip the sponza stand-in sub-record")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes for live HBM traffic")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only rehearses the multi-process path on a box with one GPU")
     args = ap.parse_args()
@@ -226,12 +396,15 @@ def main():
     args.height = args.height or dh
     args.spp = args.spp or dspp
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    # counter passes in child processes first, while this process has not touched the GPU yet
+    live_traffic = live_hbm_traffic(args, world) if rank == 0 else None
+
     import torch
     import torch.distributed as dist
     import path_tracer_amd as pta
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -239,8 +412,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
     local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -253,27 +428,34 @@ def main():
     n_pix = args.width * args.height
 
     reducer = None
-    if world > 1:
+    frame_spp = args.spp if args.strong else args.spp * world  # samples per pixel a frame adds, all ranks together
+    if collective:
         from path_tracer_amd.distributed import FrameReducer, sample_share
         deltas = [torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda") for _ in range(2)]
         master = torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
         reducer = FrameReducer(dist, deltas, master)
-        first, count = sample_share(args.spp * world, world, rank)
+        first, count = sample_share(frame_spp, world, rank)
+        # Paths that fork (translucent surfaces) can outgrow a batch's ray queues; such a batch adds nothing until
+        # it is rendered again at the next synchronisation.  That must happen before the frame's buffer goes into
+        # the reduce, so these scenes wait for the frame (and lose the overlap of reduce and next frame).
+        forks = any(m.opacity < 1.0 - 5e-5 for m in scene.materials())
 
     def step():
-        if world == 1:
+        if not collective:
             scene.pathtrace(args.spp)
         else:
             # frame k renders into buffer k % 2 while the reduce of frame k-1 is still in flight
             scene.use_external_accum(reducer.begin_frame().data_ptr())
-            scene.pathtrace_split(args.spp * world, first, count)
-            reducer.reduce(args.spp * world)
+            scene.pathtrace_split(frame_spp, first, count)
+            if forks:
+                scene.synchronize()
+            reducer.reduce(frame_spp)
 
     def fence():
         if reducer is not None:
             reducer.finish()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -340,41 +522,83 @@ def main():
     if rank == 0:
         b_ray = bytes_per_ray(n_box, n_tri, hit_frac)
         trace_s = ms[pta.TIMER_TRACE] * 1e-3
-        traffic, traffic_source = measured_traffic(args, world)
-        achieved = rays_kernel * b_ray / trace_s * 1e-9 if trace_s > 0 else 0.0
-        achieved_alone = stage_rays_kernel * b_ray / stage_trace_s * 1e-9 if stage_trace_s > 0 else 0.0
+        n_launch = max(launches[pta.TIMER_TRACE], 1)
+        avg_launch_s = trace_s / n_launch
+        in_lds = bool(scene.get_option(pta.OPT_TREE_IN_LDS))
+        tflops = fp32_tflops(n_box, n_tri, rays_kernel, trace_s)
+        tflops_alone = fp32_tflops(n_box, n_tri, stage_rays_kernel, stage_trace_s)
+        cc = committed_counters(args, world)
+        counters = summarise_counters(cc) if cc else None
+        # HBM bytes per launch: this run's own counter passes, else the committed ones of the same workload
+        traffic, traffic_source = None, None
+        if live_traffic:
+            traffic = live_traffic[0]
+            traffic_source = ("rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE child passes of this run (tools/prof_frame.py: 3 frames of the same "
+                              "workload, %d trace_kernel launches, one frame in flight; read side doubled for gfx950)" % live_traffic[1])
+        elif counters and "hbm_bytes_per_launch" in counters:
+            traffic, traffic_source = counters["hbm_bytes_per_launch"], counters["cache_source"] + " (committed; not measured in this run)"
+        # Fractions of every ceiling that applies.  A tree staged in LDS has no memory path in the walk: its operands
+        # cost vector instructions, so its bound is the FP32 peak (the HBM figure beside it is the ray and hit queues).
+        # A tree that leaves the CU is quoted against the ceiling it is closest to: FP32, vector L1 (tag look-ups at 64
+        # bytes each), L2 or HBM, the cache figures from the counter passes of the same workload.
+        fracs = {"valu": tflops / FP32_PEAK_TFLOPS}
+        hbm_gbs = traffic / stage_trace_launch_ms * 1e-6 if (traffic and stage_trace_launch_ms > 0) else None
+        if hbm_gbs is not None:
+            fracs["hbm"] = hbm_gbs / HBM_PEAK_GBS
+        if not in_lds and counters:
+            if "l2_frac_of_peak_upper_bound" in counters:
+                fracs["l2"] = counters["l2_frac_of_peak_upper_bound"]
+            if "l1_frac_of_peak" in counters:
+                fracs["l1"] = counters["l1_frac_of_peak"]
+        bound = "valu" if in_lds else max(fracs, key=lambda k: fracs[k])
+        if bound == "valu":
+            roof = {"bound": "valu", "achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fracs["valu"]}
+        elif bound == "hbm":
+            roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fracs["hbm"]}
+        elif bound == "l1":
+            roof = {"bound": "l1", "achieved": counters["l1_GBs_at_64B_per_access"], "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": fracs["l1"]}
+        else:
+            roof = {"bound": "l2", "achieved": counters["l2_GBs_upper_bound"], "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": fracs["l2"]}
+        roof.update({
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_source,
+            "kernel": "trace_kernel (closest hit)", "tree_in_lds": in_lds,
+            "fractions": fracs,
+            "fp32": {"achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS,
+                     "flop_per_ray": FLOP_PER_BOX_TEST * n_box + FLOP_PER_TRI_TEST * n_tri,
+                     "definition": "algorithmic: 27 FLOP per slab test + 75 per triangle test, tests counted by the kernel in an untimed pass"},
+            "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS if hbm_gbs is not None else None,
+                    "definition": "measured HBM bytes per launch / launch time with one frame in flight (the counter passes run that way)"},
+            "counters": counters,
+            "box_tests_per_ray": n_box, "tri_tests_per_ray": n_tri, "hit_fraction": hit_frac,
+            "launches": launches[pta.TIMER_TRACE], "avg_launch_ms": avg_launch_s * 1e3,
+            "rays_per_launch": rays_kernel / n_launch,
+            "rays_in_fused_tail_fraction": rays_tail / max(rays_local, 1.0),
+            # the survey's per-ray byte formula prices node and triangle operands as memory traffic; kept as a named
+            # figure only, because those operands come from LDS or cache and not from HBM
+            "algorithmic_operand_bytes": {"per_ray": b_ray, "per_launch": rays_kernel * b_ray / n_launch,
+                                          "rate_GBs": rays_kernel * b_ray / trace_s * 1e-9 if trace_s > 0 else 0.0},
+            "note": ("%d frames are in flight on streams of their own in the timed region, so a launch's duration includes the time it "
+                     "shares the chip with the other frames' kernels; `alone` is the same kernel with one frame in flight "
+                     "(%d untimed frames)" % (streams, stage_frames)) if streams > 1 else None,
+            "alone": {"achieved": tflops_alone, "frac": tflops_alone / FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "avg_launch_ms": stage_trace_launch_ms},
+        })
         out = {
             "metric": "Mrays/s", "value": rays_total / elapsed * 1e-6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": ("synthetic scene + synthetic probe" if args.workload == "sponza" else
                      "reference scene file + synthetic probe" if WORKLOADS[args.workload][1] else "reference scene file"),
             "config": {
-                "workload": "%s %dx%d, %d spp/frame/GPU, SAH %s, progressive" % (
+                "workload": "%s %dx%d, %d spp/frame%s, SAH %s, progressive" % (
                     args.obj or WORKLOADS[args.workload][0] or "sponza stand-in (tools/make_sponza.py)", args.width, args.height,
-                    args.spp, args.accel.upper()),
+                    frame_spp if args.strong else args.spp, "" if args.strong else "/GPU", args.accel.upper()),
                 "frames_in_flight": streams, "lane_streams_replaced": int(c[pta.CNT_STREAM_SWAPS]),
                 "parallelism": ("sample-split x%d + %s reduce of the accumulation buffer" % (
-                    world, "RCCL" if args.backend == "nccl" else "gloo (host-staged rehearsal)")) if world > 1 else "single GPU",
+                    world, "RCCL" if args.backend == "nccl" else "gloo (host-staged rehearsal)")) if collective else "single GPU",
             },
-            "spp_per_s": args.spp * world * args.steps / elapsed,
-            "rays_per_sample": rays_local / (float(n_pix) * args.spp * args.steps),
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": rays_kernel * b_ray / max(launches[pta.TIMER_TRACE], 1),
-                "kernel": "trace_kernel (closest hit)", "bytes_per_ray": b_ray,
-                "box_tests_per_ray": n_box, "tri_tests_per_ray": n_tri, "hit_fraction": hit_frac,
-                "launches": launches[pta.TIMER_TRACE], "avg_launch_ms": ms[pta.TIMER_TRACE] / max(launches[pta.TIMER_TRACE], 1),
-                "rays_per_launch": rays_kernel / max(launches[pta.TIMER_TRACE], 1),
-                "rays_in_fused_tail_fraction": rays_tail / max(rays_local, 1.0),
-                "valu": measured_valu(args, world),
-                "note": ("%d frames are in flight on streams of their own in the timed region, so a launch's duration includes the time it "
-                         "shares the chip with the other frames' kernels; `alone` is the same kernel with one frame in flight "
-                         "(%d untimed frames)" % (streams, stage_frames)) if streams > 1 else None,
-                "alone": {"achieved": achieved_alone, "frac": achieved_alone / HBM_PEAK_GBS, "avg_launch_ms": stage_trace_launch_ms},
-            },
+            "spp_per_s": frame_spp * args.steps / elapsed,
+            "rays_per_sample": rays_total / (float(n_pix) * frame_spp * args.steps),
+            "roofline": roof,
             "stage_ms_per_step": {
                 "raygen": stage_ms[pta.TIMER_RAYGEN], "trace": stage_ms[pta.TIMER_TRACE],
                 "shade": stage_ms[pta.TIMER_SHADE], "accumulate": stage_ms[pta.TIMER_ACCUM],
@@ -384,7 +608,7 @@ def main():
             "max_queue": max_queue,
         }
 
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not collective:
         if not args.no_kd and args.accel == "bvh":
             scene.close()  # its streams go first: a process's streams share a few hardware queues
             scene = None
@@ -402,13 +626,18 @@ def main():
             k1 = time.perf_counter() - k0
             out["kd_tree"] = {"Mrays/s": kd.counters()[pta.CNT_RAYS] / k1 * 1e-6, "spp_per_s": n_kd * args.spp / k1, "steps": n_kd}
             kd.close()
+        if not args.no_sponza and is_default_workload(args, world):
+            if scene is not None:
+                scene.close()
+                scene = None
+            out["sponza"] = sponza_record(pta, args, local_rank, stream.cuda_stream)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     if scene is not None:
