@@ -53,6 +53,9 @@ WORKLOADS = {
     "cornellbox-alpha": ("cornellbox-alpha.obj", True),
     "cornellball-glass": ("cornellball-glass.obj", False),
     "teapot": ("teapot.obj", True),
+    "teapot-glass": ("teapot-glass.obj", True),
+    "testobj": ("testObj.obj", True),
+    "bunny": ("bunny.obj", True),
     # procedural stand-in for the undistributed sponza.obj (tools/make_sponza.py), probe-lit
     "sponza": (None, True),
 }

@@ -1150,6 +1150,27 @@ void orc_kd_dump(void* h, int* left, int* right, int* first, int* count, float* 
     }
 }
 
+// Takes a kd-tree from outside instead of building one (arrays as orc_kd_dump writes them, same node
+// numbering).  The reference's builder is quadratic per node (src/cs488.h:1249-1294) and so is the one
+// above; for meshes too large for it the tests hand over the tree of the renderer's O(n log n) builder,
+// which they hold node for node equal to this file's builder on every mesh small enough to compare.
+// What is checked with an imported tree is the traversal (src/cs488.h:1344-1379), not the builder.
+void orc_kd_import(void* h, int n_nodes, const int* left, const int* right, const int* first, const int* count,
+                   const float* box6, const int* refs) {
+    Scene* S = (Scene*)h;
+    S->accel = 1;
+    S->mesh.precalc();
+    S->kd.mesh = &S->mesh;
+    S->kd.nodes.assign((size_t)n_nodes, KdNode());
+    for (int i = 0; i < n_nodes; i++) {
+        KdNode& nd = S->kd.nodes[i];
+        nd.left = left[i]; nd.right = right[i];
+        for (int c = 0; c < 3; c++) { nd.box.lo[c] = box6[6 * i + c]; nd.box.hi[c] = box6[6 * i + 3 + c]; }
+        if (nd.left < 0) nd.list.assign(refs + first[i], refs + first[i] + count[i]);
+    }
+    S->built = true;
+}
+
 // closest hit for a batch of rays (src/cs488.h:1750-1777); tri = -1 and t = FLT_MAX on a miss.
 // counters (optional, 24 x u64) accumulate rays, box tests, triangle tests.
 void orc_trace(void* h, int n, const float* rays6, int* tri, float* t, float* bary2, float* P3, float* N3,

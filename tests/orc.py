@@ -54,7 +54,7 @@ def lib():
         L.orc_create.restype = C.c_void_p
         for name in ("orc_destroy", "orc_single_triangle", "orc_set_tris", "orc_get_tris", "orc_get_material",
                      "orc_set_material", "orc_set_env", "orc_set_camera", "orc_set_max_level", "orc_build",
-                     "orc_bvh_dump", "orc_kd_dump", "orc_trace", "orc_camera_rays", "orc_radiance", "orc_ibl",
+                     "orc_bvh_dump", "orc_kd_dump", "orc_kd_import", "orc_trace", "orc_camera_rays", "orc_radiance", "orc_ibl",
                      "orc_reset", "orc_get_image", "orc_pcg32"):
             getattr(L, name).restype = None
         _lib = L
@@ -164,6 +164,15 @@ class Oracle:
         self.L.orc_build(self.h, int(accel))
 
     # ---- accelerator dumps ----
+    def import_kd(self, tree):
+        """Uses a kd-tree built elsewhere (the dict Scene.get_tree() returns: the renderer's host builder) in place
+        of this oracle's quadratic builder; for meshes too large for the latter."""
+        n = len(tree["left"])
+        arrs = [np.ascontiguousarray(tree[k], np.int32) for k in ("left", "right", "first", "count")]
+        box = np.ascontiguousarray(tree["box"], np.float32)
+        refs = np.ascontiguousarray(tree["refs"] if len(tree["refs"]) else np.zeros(1), np.int32)
+        self.L.orc_kd_import(self.h, n, *[_ip(a) for a in arrs], _fp(box), _ip(refs))
+
     def bvh_dump(self):
         n = self.L.orc_bvh_num_nodes(self.h)
         r = self.L.orc_bvh_num_refs(self.h)
