@@ -243,6 +243,11 @@ int pt_trace_batch_static(PtContext* ctx, int n, const float* d_rays6, int32_t* 
  * (src/cs488.h:1780-1794), n = W*H rays in pixel order; for tests of the camera model. */
 int pt_camera_rays(PtContext* ctx, float* rays6);
 
+/* Scene::generateRay (src/cs488.h:1825-1839) as the ray-generation kernel evaluates it: for the global sample index
+ * `sample` (0 = the first sample after pt_reset) the jittered camera ray of every pixel, n = W*H rays in pixel order,
+ * read back from the ray queue the kernel wrote.  For parity tests of the kernel; renders nothing. */
+int pt_camera_samples(PtContext* ctx, int sample, float* rays6);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 int pt_get_counters(PtContext* ctx, uint64_t out[PT_CNT_COUNT]);
 int pt_reset_counters(PtContext* ctx);

@@ -39,7 +39,7 @@ EXPORTS = [
     "pt_get_env", "pt_build", "pt_get_tree", "pt_set_camera", "pt_set_resolution", "pt_reset", "pt_render",
     "pt_render_split", "pt_resolve", "pt_total_samples", "pt_synchronize", "pt_download", "pt_accum_device_ptr",
     "pt_use_external_accum", "pt_save_png", "pt_save_pfm", "pt_trace_batch", "pt_camera_rays", "pt_get_counters",
-    "pt_reset_counters", "pt_get_timers", "pt_trace_batch_static", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
+    "pt_reset_counters", "pt_get_timers", "pt_trace_batch_static", "pt_camera_samples", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
 ]
 
 
@@ -320,6 +320,12 @@ class Scene:
     def camera_rays(self):
         rays = np.zeros((self.width * self.height, 6), np.float32)
         self._check(self.L.pt_camera_rays(self.h, _fp(rays)))
+        return rays
+
+    def camera_samples(self, sample=0):
+        """The jittered camera rays raygen_kernel generates for one global sample index (W*H x 6, pixel order)."""
+        rays = np.zeros((self.width * self.height, 6), np.float32)
+        self._check(self.L.pt_camera_samples(self.h, int(sample), _fp(rays)))
         return rays
 
     # ---- measurement ----

@@ -122,6 +122,9 @@ struct LaunchCfg {
 // ---- launchers (each returns the hipError_t of the launch) ----
 hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const BatchGpu& batch, QueueSet out,
                          float4* sample_rad, int* qcount);
+// the camera rays of a one-sample-per-pixel batch, from the queue raygen wrote, in pixel order (n_pixels x 6 floats)
+hipError_t launch_gather_camera_rays(const LaunchCfg& cfg, const CameraGpu& cam, const BatchGpu& batch, const float4* ray_d,
+                                     const int* qcount, float* rays6);
 // One workgroup per queue region: `grid_blocks` regions of `cap_block` entries.  With n_rays ==
 // nullptr the input is one flat array of n_fixed rays cut into consecutive regions.
 hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int count_tests, int fast_slab,

@@ -575,6 +575,21 @@ int check_lanes(PtContext* c) {
     return PT_OK;
 }
 
+// How a batch is cut into workgroup regions: about 2048 camera samples each, at most the resident grid.
+void shape_batch(PtContext* c, const Lane& ln, bool own_stream, BatchGpu& b) {
+    int nb = (b.n_slots + 2047) / 2048;
+    if (c->resident_per_cu <= 0) c->resident_per_cu = trace_resident_blocks_per_cu(c->scene, c->accel == PT_ACCEL_KD, c->traversal);
+    // with another batch in flight beside this one, five regions per CU leave its kernels room (measured: 5 or 6
+    // instead of 8 gains 3-5 % on the cornellbox and the teapot, nothing elsewhere)
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (own_stream && c->resident_per_cu > 5 ? 5 : c->resident_per_cu);
+    const int most = c->cus * per_cu;
+    nb = nb < 1 ? 1 : (nb > most ? most : nb);
+    b.blocks = nb;
+    b.slots_block = (((b.n_slots + 63) / 64 + nb - 1) / nb) * 64;  // runs of 64 samples dealt in rounds
+    b.deal_shift = nb > 2 ? ((int)(nb * 0.6180339887) | 1) : 0;
+    b.cap_block = (int)((ln.batch_alloc * (size_t)c->queue_factor) / (size_t)nb);
+}
+
 // One wavefront batch: camera rays, then trace + shade per bounce level on the batch's lane, then
 // accumulate on the context's stream.
 int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int sample0, int chunk) {
@@ -594,18 +609,8 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
             if (rc != PT_OK) return rc;
         }
     }
-    // workgroups sharing the batch: about 2048 camera samples each, at most the resident grid
-    int nb = (b.n_slots + 2047) / 2048;
-    if (c->resident_per_cu <= 0) c->resident_per_cu = trace_resident_blocks_per_cu(c->scene, c->accel == PT_ACCEL_KD, c->traversal);
-    // with another batch in flight beside this one, five regions per CU leave its kernels room (measured: 5 or 6
-    // instead of 8 gains 3-5 % on the cornellbox and the teapot, nothing elsewhere)
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (own_stream && c->resident_per_cu > 5 ? 5 : c->resident_per_cu);
-    const int most = c->cus * per_cu;
-    nb = nb < 1 ? 1 : (nb > most ? most : nb);
-    b.blocks = nb;
-    b.slots_block = (((b.n_slots + 63) / 64 + nb - 1) / nb) * 64;  // runs of 64 samples dealt in rounds
-    b.deal_shift = nb > 2 ? ((int)(nb * 0.6180339887) | 1) : 0;
-    b.cap_block = (int)((ln.batch_alloc * (size_t)c->queue_factor) / (size_t)nb);
+    shape_batch(c, ln, own_stream, b);
+    const int nb = b.blocks;
     IssuedBatch rec;
     rec.cam = cam; rec.pixel0 = pixel0; rec.n_pixels = n_pixels; rec.sample0 = sample0; rec.chunk = chunk;
     rec.flag = (int)(c->batch_seq++ % FLAG_RING);
@@ -1322,6 +1327,41 @@ int pt_camera_rays(PtContext* c, float* rays6) {
         }
     }
     return PT_OK;
+}
+
+// The camera rays the ray-generation kernel draws for one global sample index, one per pixel, in pixel order.
+int pt_camera_samples(PtContext* c, int sample, float* rays6) {
+    PT_TRY
+    if (!c || !rays6 || sample < 0) return fail(c, PT_ERR_INVALID_ARG, "pt_camera_samples: bad arguments");
+    if (c->device == PT_DEVICE_NONE || !c->built) return fail(c, PT_ERR_NOT_READY, "pt_build has not been called");
+    if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
+    const size_t n_pixels = (size_t)c->width * c->height;
+    if (n_pixels > c->max_batch) return fail(c, PT_ERR_INVALID_ARG, "pt_camera_samples: more pixels than PT_OPT_MAX_BATCH");
+    int rc = settle(c);  // the lanes are idle after this
+    if (rc != PT_OK) return rc;
+    Lane& ln = c->lanes[0];
+    rc = ensure_lane(c, ln, n_pixels);
+    if (rc != PT_OK) return rc;
+    CameraGpu cam;
+    camera_of(c, cam);
+    BatchGpu b;
+    b.pixel0 = 0; b.n_pixels = (int)n_pixels; b.chunk = 1; b.sample0 = sample; b.seed = c->seed; b.n_slots = (int)n_pixels;
+    shape_batch(c, ln, c->n_lanes > 1, b);
+    PT_HIP(c, ln.d_keys.ensure(1024));
+    PT_HIP(c, ln.d_eye.ensure(1));
+    PT_HIP(c, ln.d_qcount.ensure(((size_t)c->max_level + 3) * (size_t)c->blocks));
+    b.keys = ln.d_keys.ptr;
+    b.overflow = c->d_batch_flags.ptr + (int)(c->batch_seq++ % FLAG_RING);
+    QueueSet out;
+    out.ray_o = ln.d_eye.ptr; out.ray_d = ln.q_ray_d[0].ptr; out.beta = nullptr;
+    const LaunchCfg cfg = cfg_of(c);
+    PT_HIP(c, c->tb_rays.ensure(6 * n_pixels));
+    PT_HIP(c, launch_raygen(cfg, cam, b, out, ln.d_sample_rad.ptr, ln.d_qcount.ptr));
+    PT_HIP(c, launch_gather_camera_rays(cfg, cam, b, out.ray_d, ln.d_qcount.ptr, c->tb_rays.ptr));
+    PT_HIP(c, hipMemcpyAsync(rays6, c->tb_rays.ptr, sizeof(float) * 6 * n_pixels, hipMemcpyDeviceToHost, c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+    PT_CATCH(c)
 }
 
 // ---- measurement ----

@@ -60,6 +60,26 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
     }
 }
 
+// The camera rays raygen_kernel left in the queue, put back into pixel order (for parity tests of the kernel
+// itself): walks the same dealing as raygen_kernel and writes (eye, direction) of every sample of a batch with one
+// sample per pixel to rays6[6 * (pixel - pixel0)].
+__global__ __launch_bounds__(256) void gather_camera_rays_kernel(CameraGpu cam, BatchGpu b, const float4* __restrict__ ray_d,
+                                                                 const int* __restrict__ qcount, float* __restrict__ rays6) {
+    const int blk = blockIdx.x;
+    const int n = qcount[blk];
+    const size_t region = (size_t)blk * b.cap_block;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const int l = j >> 6;
+        const int slot = (l * b.blocks + dealt_position(blk, l, b)) * 64 + (j & 63);
+        int pixel, k;
+        slot_to_sample(b, slot, pixel, k);
+        const float4 d = ray_d[region + j];
+        float* out = rays6 + 6 * (size_t)(pixel - b.pixel0);
+        out[0] = cam.eye[0]; out[1] = cam.eye[1]; out[2] = cam.eye[2];
+        out[3] = d.x; out[4] = d.y; out[5] = d.z;
+    }
+}
+
 // Sampler keys of the batch's sample indices (they depend on the seed and the global sample index
 // only, so they are hashed once per batch instead of once per path and bounce).
 __global__ void sample_keys_kernel(uint64_t seed, int sample0, int chunk, uint64_t* __restrict__ keys) {
@@ -171,6 +191,12 @@ hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const Batch
     hipLaunchKernelGGL(sample_keys_kernel, dim3((batch.chunk + 255) / 256), dim3(256), 0, cfg.stream, batch.seed, batch.sample0,
                        batch.chunk, const_cast<uint64_t*>(batch.keys));
     hipLaunchKernelGGL(raygen_kernel, dim3(batch.blocks), dim3(256), 0, cfg.stream, cam, batch, out, sample_rad, qcount);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_camera_rays(const LaunchCfg& cfg, const CameraGpu& cam, const BatchGpu& batch, const float4* ray_d,
+                                     const int* qcount, float* rays6) {
+    hipLaunchKernelGGL(gather_camera_rays_kernel, dim3(batch.blocks), dim3(256), 0, cfg.stream, cam, batch, ray_d, qcount, rays6);
     return hipGetLastError();
 }
 

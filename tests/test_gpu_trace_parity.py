@@ -52,8 +52,10 @@ def test_ray_batch_parity(gpu_device, obj, accel):
 
 
 @pytest.mark.parametrize("accel", [orc.BVH, orc.KD])
-def test_camera_rays_parity(gpu_device, accel):
-    """All 512x384 pixel-centre camera rays of the default camera."""
+def test_host_camera_model_and_pixel_centre_rays(gpu_device, accel):
+    """All 512x384 pixel-centre camera rays of the default camera: the rays come from the library's HOST camera
+    model (pt_camera_rays, the reference's eyeRay form) and are compared with the oracle's, then traced on the
+    GPU.  The ray-generation KERNEL is checked in tests/test_gpu_raygen.py."""
     o = load_oracle_scene("cornellbox.obj", accel)
     s = load_gpu_scene("cornellbox.obj", accel)
     s.set_resolution(512, 384)
