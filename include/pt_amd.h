@@ -20,6 +20,7 @@ extern "C" {
 #endif
 
 typedef struct PtContext PtContext;
+typedef struct PtGroup PtGroup;
 
 typedef enum PtStatus {
     PT_OK = 0,
@@ -223,6 +224,27 @@ int pt_record_frame(PtContext* ctx);
 int pt_record_end(PtContext* ctx);
 /* The same encoder on caller-supplied frames (n_frames x height x width x 3 bytes, rows top-down); needs no GPU. */
 int pt_encode_gif(const char* path, const uint8_t* rgb8, int n_frames, int width, int height, int delay_cs);
+
+/* ---- several GPUs: the thread pool of Scene::Pathtrace (src/cs488.h:1885-1895) ---------------- */
+/* The reference splits a frame over numThreads threads by image columns and joins them (src/cs488.h:1885-1895).
+ * Here a frame is split over the GPUs of one node by SAMPLES: a group is n contexts of this process, one per GPU,
+ * holding the same scene, accelerator, camera, options and resolution (the caller sets each of them up alike);
+ * member r renders sample indices sample_share(spp, n, r) of every pixel into a per-frame buffer on its GPU, and ONE
+ * RCCL ncclReduce(float, sum) per frame over xGMI adds those buffers onto members[0], which folds the sum into its
+ * accumulation buffer and resolves its frame buffer.  The sampler is keyed by (pixel, global sample index), so the
+ * image equals the single-GPU one up to the order of the float additions.  Everything is queued on the members'
+ * streams; pt_group_synchronize (or pt_download on members[0]) waits.  While a context is in a group it is driven
+ * through the group calls only (plus pt_set_camera, pt_download / pt_save_* on members[0], counters and timers);
+ * pt_group_destroy releases the communicators and returns the contexts to stand-alone use. */
+int pt_group_create(int n, PtContext* const* members, PtGroup** out);
+void pt_group_destroy(PtGroup* group);
+const char* pt_group_last_error(PtGroup* group);
+int pt_group_size(PtGroup* group);
+/* One progressive frame over all members: totalSamples += spp on each of them (src/cs488.h:1882). */
+int pt_group_render(PtGroup* group, int spp);
+/* FrameBuffer.clear + AccumulationBuffer.clear + totalSamples = 0 on every member (src/cs488.h:2288-2290) */
+int pt_group_reset(PtGroup* group);
+int pt_group_synchronize(PtGroup* group);
 
 /* ---- parity entry: Scene::intersect on a batch of rays (src/cs488.h:1750-1777) ------------- */
 /* rays6: n x (origin xyz, direction xyz) in host memory.  tri: index of the winning triangle in

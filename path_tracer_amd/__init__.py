@@ -39,7 +39,8 @@ EXPORTS = [
     "pt_get_env", "pt_build", "pt_get_tree", "pt_set_camera", "pt_set_resolution", "pt_reset", "pt_render",
     "pt_render_split", "pt_resolve", "pt_total_samples", "pt_synchronize", "pt_download", "pt_accum_device_ptr",
     "pt_use_external_accum", "pt_save_png", "pt_save_pfm", "pt_trace_batch", "pt_camera_rays", "pt_get_counters",
-    "pt_reset_counters", "pt_get_timers", "pt_trace_batch_static", "pt_camera_samples", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
+    "pt_reset_counters", "pt_get_timers", "pt_trace_batch_static", "pt_camera_samples", "pt_group_create", "pt_group_destroy", "pt_group_last_error",
+    "pt_group_size", "pt_group_render", "pt_group_reset", "pt_group_synchronize", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
 ]
 
 
@@ -81,6 +82,8 @@ def lib():
         L.pt_last_error.restype = C.c_char_p
         L.pt_accum_device_ptr.restype = C.c_void_p
         L.pt_destroy.restype = None
+        L.pt_group_destroy.restype = None
+        L.pt_group_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -342,3 +345,42 @@ class Scene:
         n = (C.c_uint64 * TIMER_COUNT)()
         self._check(self.L.pt_get_timers(self.h, ms, n))
         return [float(x) for x in ms], [int(x) for x in n]
+
+
+class Group:
+    """Several Scenes of this process, one per GPU, rendering one image: every frame's samples are split over
+    the members and summed onto scenes[0] with one RCCL reduce (pt_group_*).  Set the members up alike first."""
+
+    def __init__(self, scenes):
+        self.L = lib()
+        self.scenes = list(scenes)
+        arr = (C.c_void_p * len(self.scenes))(*[s.h for s in self.scenes])
+        self.h = C.c_void_p()
+        rc = self.L.pt_group_create(len(self.scenes), arr, C.byref(self.h))
+        if rc != PT_OK:
+            raise PtError(rc, (self.L.pt_last_error(self.scenes[0].h) or b"").decode(errors="replace") if self.scenes else "empty group")
+
+    def _check(self, rc):
+        if rc < 0:
+            raise PtError(rc, (self.L.pt_group_last_error(self.h) or b"").decode(errors="replace"))
+        return rc
+
+    def pathtrace(self, spp=10):
+        self._check(self.L.pt_group_render(self.h, int(spp)))
+
+    def reset(self):
+        self._check(self.L.pt_group_reset(self.h))
+
+    def synchronize(self):
+        self._check(self.L.pt_group_synchronize(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

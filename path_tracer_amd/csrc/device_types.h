@@ -147,6 +147,7 @@ hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int
                         unsigned long long* totals);
 hipError_t launch_resolve(const LaunchCfg& cfg, const float* accum, float* frame, int n_pixels, int total_samples);
 hipError_t launch_clear(const LaunchCfg& cfg, float* buf, size_t n);
+hipError_t launch_add(const LaunchCfg& cfg, float* dst, const float* src, size_t n);  // dst += src
 // a single wave that stays busy for about `microseconds` (to probe whether two streams overlap)
 hipError_t launch_spin(const LaunchCfg& cfg, int microseconds);
 // unpacks rays6 (n x 6 floats) into queue form for the batch-trace entry

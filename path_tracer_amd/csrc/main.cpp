@@ -17,7 +17,9 @@
 // FrameBuffer.save, src/cs488.h:249-253), --seed N, --device N, --stats (ray statistics and
 // Mrays/s on stderr after the last frame), --sequence PREFIX (every frame to PREFIX%04d.png),
 // --obj-polygons (faces with more than three vertices as triangle fans, negative indices; the
-// reference reads three vertices per face, src/cs488.h:1059).
+// reference reads three vertices per face, src/cs488.h:1059), --gpus N (the frame's samples are split over
+// GPUs device .. device+N-1 of this node and summed onto the first with one RCCL reduce per frame, in place of the
+// reference's column-strip threads, src/cs488.h:1885-1895; the output lines stay the same).
 //
 // Window input is replaced by a script (--script FILE), one event per line, applied where the
 // reference polls events, i.e. before the frame with that index is rendered (src/cs488.h:2283):
@@ -46,6 +48,7 @@ namespace {
 struct Options {
     std::vector<std::string> positional;
     int width = 512, height = 384, spp = 10, frames = 10, accel = PT_ACCEL_KD, device = 0, max_level = 15;
+    int gpus = 0;  // 0: one context, no group; N >= 1: a group of N contexts (N = 1 still goes through the reduce)
     bool progressive = true, stats = false;
     bool have_seed = false;
     uint64_t seed = 0;
@@ -117,7 +120,7 @@ void usage() {
     fprintf(stderr,
             "usage: CS488 <scene.obj> [probe.hdr] [--accel kd|bvh] [--spp N] [--width W --height H] [--frames N]\n"
             "             [--out frame.png|frame.pfm] [--no-progressive] [--max-level N] [--eye x y z] [--lookat x y z]\n"
-            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--stats] [--headless]\n"
+            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--gpus N] [--stats] [--headless]\n"
             "             [--script events.txt] [--sequence PREFIX] [--obj-polygons]\n");
 }
 
@@ -136,6 +139,7 @@ bool parse(int argc, const char* argv[], Options& o) {
         else if (a == "--frames") { if (!need(i, 1)) return false; o.frames = atoi(argv[++i]); }
         else if (a == "--max-level") { if (!need(i, 1)) return false; o.max_level = atoi(argv[++i]); }
         else if (a == "--device") { if (!need(i, 1)) return false; o.device = atoi(argv[++i]); }
+        else if (a == "--gpus") { if (!need(i, 1)) return false; o.gpus = atoi(argv[++i]); if (o.gpus < 1 || o.gpus > 64) { usage(); return false; } }
         else if (a == "--seed") { if (!need(i, 1)) return false; o.seed = strtoull(argv[++i], nullptr, 0); o.have_seed = true; }
         else if (a == "--fov") { if (!need(i, 1)) return false; o.fov = (float)atof(argv[++i]); }
         else if (a == "--out") { if (!need(i, 1)) return false; o.out = argv[++i]; }
@@ -158,9 +162,28 @@ int save_frame(PtContext* ctx, const std::string& path) {
     return rc;
 }
 
-int die(PtContext* ctx, const char* what, int rc) {
-    fprintf(stderr, "%s failed (%d): %s\n", what, rc, ctx ? pt_last_error(ctx) : "");
-    if (ctx) pt_destroy(ctx);
+// Everything that has to be the same on every GPU of a group is done through these: the call on every context, the
+// first failure returned.
+struct Contexts {
+    std::vector<PtContext*> all;
+    PtGroup* group = nullptr;
+    PtContext* root() const { return all.empty() ? nullptr : all[0]; }
+    template <typename F> int each(F f) {
+        for (PtContext* c : all) { const int rc = f(c); if (rc != PT_OK) return rc; }
+        return PT_OK;
+    }
+    void destroy() {
+        if (group) pt_group_destroy(group);
+        group = nullptr;
+        for (PtContext* c : all) pt_destroy(c);
+        all.clear();
+    }
+};
+
+int die(Contexts& cs, const char* what, int rc) {
+    const char* why = cs.group && pt_group_last_error(cs.group)[0] ? pt_group_last_error(cs.group) : (cs.root() ? pt_last_error(cs.root()) : "");
+    fprintf(stderr, "%s failed (%d): %s\n", what, rc, why);
+    cs.destroy();
     return 1;
 }
 
@@ -170,37 +193,44 @@ int main(int argc, const char* argv[]) {
     Options opt;
     if (!parse(argc, argv, opt)) return 2;
 
-    PtContext* ctx = nullptr;
-    int rc = pt_create(opt.device, &ctx);
-    if (rc != PT_OK) {
-        fprintf(stderr, "No usable GPU (device %d): this program renders on an AMD GPU only.\n", opt.device);
-        return 1;
+    Contexts cs;
+    int rc = PT_OK;
+    for (int g = 0; g < (opt.gpus > 0 ? opt.gpus : 1); g++) {
+        PtContext* c = nullptr;
+        rc = pt_create(opt.device + g, &c);
+        if (rc != PT_OK) {
+            fprintf(stderr, "No usable GPU (device %d): this program renders on an AMD GPU only.\n", opt.device + g);
+            cs.destroy();
+            return 1;
+        }
+        cs.all.push_back(c);
     }
+    PtContext* ctx = cs.root();  // the context whose frame buffer is shown, saved and recorded
 
     // setupScene, src/main.cpp:6-27
     if (!opt.positional.empty()) {
         const char* obj = opt.positional[0].c_str();
-        if (opt.obj_extended) pt_set_option(ctx, PT_OPT_OBJ_EXTENDED, 1);
+        if (opt.obj_extended) cs.each([&](PtContext* c) { return pt_set_option(c, PT_OPT_OBJ_EXTENDED, 1); });
         printf("Loading \"%s\"...\n", obj);  // src/cs488.h:712
-        rc = pt_load_obj(ctx, obj);
+        rc = cs.each([&](PtContext* c) { return pt_load_obj(c, obj); });
         if (rc == PT_OK) {
             printf("Loaded \"%s\" with %d triangles.\n", obj, pt_num_triangles(ctx));  // src/cs488.h:779
         } else if (rc == PT_ERR_IO || rc == PT_ERR_INVALID_OBJ) {
             if (rc == PT_ERR_IO) printf("Cannot open \"%s\" for reading\n", obj);  // src/cs488.h:961
             printf("Invalid .obj file.\n");
             printf("Making a single triangle instead.\n");
-            pt_single_triangle(ctx);
+            cs.each([&](PtContext* c) { return pt_single_triangle(c); });
         } else {
-            return die(ctx, "pt_load_obj", rc);
+            return die(cs, "pt_load_obj", rc);
         }
     } else {
         printf("Specify .obj file in the command line arguments. Example: CS488.exe cornellbox.obj\n");
         printf("Making a single triangle instead.\n");
-        pt_single_triangle(ctx);
+        cs.each([&](PtContext* c) { return pt_single_triangle(c); });
     }
     if (opt.positional.size() > 1) {
         const char* hdr = opt.positional[1].c_str();
-        rc = pt_load_env(ctx, hdr);
+        rc = cs.each([&](PtContext* c) { return pt_load_env(c, hdr); });
         if (rc == PT_OK) printf("Loaded \"%s\".\n", hdr);                     // src/cs488.h:217
         else std::cerr << "Unable to load: " << hdr << std::endl;             // src/cs488.h:204
     }
@@ -208,19 +238,25 @@ int main(int argc, const char* argv[]) {
     // CS488Window::start -> Scene::preCalc, src/cs488.h:2272, 1733-1747
     printf(opt.accel == PT_ACCEL_KD ? "Building KdTree...\n" : "Building BVH...\n");  // src/cs488.h:1389,1662
     fflush(stdout);
-    if (opt.have_seed) pt_set_option(ctx, PT_OPT_SEED, opt.seed);
-    pt_set_option(ctx, PT_OPT_MAX_LEVEL, (uint64_t)opt.max_level);
-    if (opt.stats) pt_set_option(ctx, PT_OPT_COUNT_TESTS, 1);
-    rc = pt_build(ctx, opt.accel);
-    if (rc != PT_OK) return die(ctx, "pt_build", rc);
+    rc = cs.each([&](PtContext* c) {
+        if (opt.have_seed) pt_set_option(c, PT_OPT_SEED, opt.seed);
+        pt_set_option(c, PT_OPT_MAX_LEVEL, (uint64_t)opt.max_level);
+        if (opt.stats) pt_set_option(c, PT_OPT_COUNT_TESTS, 1);
+        return pt_build(c, opt.accel);
+    });
+    if (rc != PT_OK) return die(cs, "pt_build", rc);
     printf("Done.\n");
-    rc = pt_set_resolution(ctx, opt.width, opt.height);
-    if (rc != PT_OK) return die(ctx, "pt_set_resolution", rc);
+    rc = cs.each([&](PtContext* c) { return pt_set_resolution(c, opt.width, opt.height); });
+    if (rc != PT_OK) return die(cs, "pt_set_resolution", rc);
+    if (opt.gpus > 0) {
+        rc = pt_group_create((int)cs.all.size(), cs.all.data(), &cs.group);
+        if (rc != PT_OK) return die(cs, "pt_group_create", rc);
+    }
 
     std::vector<Event> events;
     if (!opt.script.empty() && !read_script(opt.script, events)) {
         fprintf(stderr, "cannot read the event script \"%s\"\n", opt.script.c_str());
-        pt_destroy(ctx);
+        cs.destroy();
         return 2;
     }
 
@@ -249,13 +285,13 @@ int main(int argc, const char* argv[]) {
                 else if (k == "I") {
                     char name[64];
                     snprintf(name, sizeof(name), "output%d.png", int(1000.0 * names.rand()));
-                    if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(ctx, "saving the frame", rc);
+                    if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(cs, "saving the frame", rc);
                 } else if (k == "F") {
                     if (!recording) {
                         char name[64];
                         snprintf(name, sizeof(name), "output%d.gif", int(1000.0 * names.rand()));  // src/cs488.h:258
                         printf("Saving \"%s\"...\n", name);
-                        if ((rc = pt_record_begin(ctx, name, 1)) != PT_OK) return die(ctx, "opening the recording", rc);
+                        if ((rc = pt_record_begin(ctx, name, 1)) != PT_OK) return die(cs, "opening the recording", rc);
                         recording = true;
                         printf("(Recording started)\n");
                     } else {
@@ -274,31 +310,33 @@ int main(int argc, const char* argv[]) {
                 lookat = eye + view;
                 right = cross(view, up);
             } else if (e.kind == "save") {
-                if ((rc = save_frame(ctx, e.arg)) != PT_OK) return die(ctx, "saving the frame", rc);
+                if ((rc = save_frame(ctx, e.arg)) != PT_OK) return die(cs, "saving the frame", rc);
             }
         }
         if (quit) break;
         view = normalize(lookat - eye);           // src/cs488.h:2284-2285
         right = normalize(cross(view, up));
         const float e3[3] = {eye.x, eye.y, eye.z}, l3[3] = {lookat.x, lookat.y, lookat.z}, u3[3] = {up.x, up.y, up.z};
-        rc = pt_set_camera(ctx, e3, l3, u3, opt.fov, 0.032f);
-        if (rc != PT_OK) return die(ctx, "pt_set_camera", rc);
+        rc = cs.each([&](PtContext* c) { return pt_set_camera(c, e3, l3, u3, opt.fov, 0.032f); });
+        if (rc != PT_OK) return die(cs, "pt_set_camera", rc);
         if (differs(prev_view, view) || differs(prev_right, right) || !opt.progressive) {  // src/cs488.h:2287-2293
-            rc = pt_reset(ctx);
-            if (rc != PT_OK) return die(ctx, "pt_reset", rc);
+            rc = cs.group ? pt_group_reset(cs.group) : pt_reset(ctx);
+            if (rc != PT_OK) return die(cs, "pt_reset", rc);
             prev_view = view;
             prev_right = right;
         }
-        rc = pt_render(ctx, opt.spp);
+        // Scene::Pathtrace, src/cs488.h:1878-1897: on one GPU, or split by samples over the group with one reduce
+        rc = cs.group ? pt_group_render(cs.group, opt.spp) : pt_render(ctx, opt.spp);
+        if (rc == PT_OK) rc = cs.group ? pt_group_synchronize(cs.group) : PT_OK;
         if (rc == PT_OK) rc = pt_synchronize(ctx);
-        if (rc != PT_OK) return die(ctx, "pt_render", rc);
+        if (rc != PT_OK) return die(cs, "pt_render", rc);
         std::cout << pt_total_samples(ctx) << std::endl;  // src/cs488.h:1896
         if (recording || !opt.sequence.empty()) {
             char name[1200];
-            if (recording && (rc = pt_record_frame(ctx)) != PT_OK) return die(ctx, "saving a recorded frame", rc);
+            if (recording && (rc = pt_record_frame(ctx)) != PT_OK) return die(cs, "saving a recorded frame", rc);
             if (!opt.sequence.empty()) {
                 snprintf(name, sizeof(name), "%s%04d.png", opt.sequence.c_str(), frame);
-                if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(ctx, "saving a sequence frame", rc);
+                if ((rc = pt_save_png(ctx, 1, name)) != PT_OK) return die(cs, "saving a sequence frame", rc);
             }
         }
         names.rand();  // src/cs488.h:2317
@@ -309,10 +347,16 @@ int main(int argc, const char* argv[]) {
         std::cout << seconds << std::endl;  // src/cs488.h:2322
     }
 
-    if (!opt.out.empty() && (rc = save_frame(ctx, opt.out)) != PT_OK) return die(ctx, "saving the frame", rc);
+    if (!opt.out.empty() && (rc = save_frame(ctx, opt.out)) != PT_OK) return die(cs, "saving the frame", rc);
     if (opt.stats) {
-        uint64_t cnt[PT_CNT_COUNT];
-        if (pt_get_counters(ctx, cnt) == PT_OK && total_seconds > 0) {
+        uint64_t cnt[PT_CNT_COUNT] = {};
+        bool have = true;
+        for (PtContext* c : cs.all) {  // a group's members each count the rays of their own share of the samples
+            uint64_t one[PT_CNT_COUNT];
+            have = have && pt_get_counters(c, one) == PT_OK;
+            for (int k = 0; k < PT_CNT_COUNT; k++) cnt[k] += one[k];
+        }
+        if (have && total_seconds > 0) {
             const double rays = (double)cnt[PT_CNT_RAYS];
             fprintf(stderr, "rays %.0f  samples %.0f  rays/sample %.3f  box tests/ray %.2f  tri tests/ray %.2f  dropped NaN samples %llu\n",
                     rays, (double)cnt[PT_CNT_SAMPLES], rays / (double)cnt[PT_CNT_SAMPLES], cnt[PT_CNT_BOX_TESTS] / rays,
@@ -321,6 +365,6 @@ int main(int argc, const char* argv[]) {
                     (double)opt.spp * frames_done / total_seconds, frames_done, total_seconds);
         }
     }
-    pt_destroy(ctx);
+    cs.destroy();
     return 0;
 }

@@ -4,6 +4,8 @@
 // There is no CPU rendering path in this library: every entry that produces pixels or hits
 // launches HIP kernels, and pt_create fails when no GPU can be opened.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <cfloat>
 #include <chrono>
@@ -54,6 +56,8 @@ struct DeviceBuffer {
 };
 
 }  // namespace
+
+struct PtGroup;
 
 // What is needed to render a batch again should its overflow flag turn out set.
 struct IssuedBatch {
@@ -133,6 +137,7 @@ struct PtContext {
     // film and queues
     DeviceBuffer<float> d_accum, d_frame;
     float* ext_accum = nullptr;
+    PtGroup* group = nullptr;             // set while the context is a member of a multi-GPU group
     Lane lanes[MAX_LANES];
     int n_lanes = 2;                      // batches in flight (PT_OPT_STREAMS)
     bool lanes_checked = false;           // the lanes' streams have been probed for running side by side
@@ -814,6 +819,7 @@ int pt_create(int device, PtContext** out) {
 
 void pt_destroy(PtContext* c) {
     if (!c) return;
+    if (c->group) return;  // destroy the group first: it holds streams and buffers of this context
     if (c->device == PT_DEVICE_NONE) { delete c; return; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -1160,7 +1166,9 @@ int pt_download(PtContext* c, int which, float* dst) {
     int rc = pt_synchronize(c);
     if (rc != PT_OK) return rc;
     const size_t n = (size_t)c->width * c->height * 3;
-    PT_HIP(c, hipMemcpy(dst, which == 0 ? c->accum_ptr() : c->d_frame.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
+    // (a member of a group renders every frame into the group's per-frame buffer; its accumulation is the internal one)
+    const float* accum = c->group ? c->d_accum.ptr : c->accum_ptr();
+    PT_HIP(c, hipMemcpy(dst, which == 0 ? accum : c->d_frame.ptr, n * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
     PT_CATCH(c)
 }
@@ -1420,5 +1428,200 @@ int pt_get_timers(PtContext* c, double ms[PT_TIMER_COUNT], uint64_t launches[PT_
     }
     return PT_OK;
 }
+
+
+// ---- several GPUs in one process: sample split and one RCCL reduce per frame ----------------------
+}  // extern "C"
+
+struct PtGroup {
+    std::vector<PtContext*> members;      // members[0] is the root
+    std::vector<ncclComm_t> comms;        // one communicator handle per member (ncclCommInitAll)
+    std::vector<float*> delta;            // per member, on its GPU: the samples it added in the current frame
+    size_t n_floats = 0;
+    bool forks = false;                   // the scene has translucent surfaces: ray queues may overflow
+    uint64_t frames = 0;
+    std::string error;
+};
+
+namespace {
+
+int gfail(PtGroup* g, int code, const std::string& msg) {
+    if (g) g->error = msg;
+    return code;
+}
+
+#define PT_GHIP(g, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) return gfail(g, PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+#define PT_GNCCL(g, call)                                                                         \
+    do {                                                                                          \
+        ncclResult_t r__ = (call);                                                                \
+        if (r__ != ncclSuccess) return gfail(g, PT_ERR_RCCL, std::string(#call) + ": " + ncclGetErrorString(r__)); \
+    } while (0)
+
+// RCCL announces itself (version, host, library path) on standard output when a communicator is made.  A host that
+// speaks a line protocol on stdout -- the reference's per-frame sample count and seconds -- cannot have that, so while
+// the communicators are set up file descriptor 1 points at descriptor 2.
+struct StdoutToStderr {
+    int saved;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
+    }
+};
+
+// rank r's share of a frame's samples: contiguous ranges, the first spp % n ranks take one more
+void sample_share(int spp, int n, int r, int& first, int& count) {
+    const int base = spp / n, extra = spp % n;
+    first = r * base + (r < extra ? r : extra);
+    count = base + (r < extra ? 1 : 0);
+}
+
+void release_group(PtGroup* g) {
+    for (size_t i = 0; i < g->members.size(); i++) {
+        PtContext* c = g->members[i];
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (i < g->comms.size() && g->comms[i]) (void)ncclCommDestroy(g->comms[i]);
+        if (i < g->delta.size() && g->delta[i]) (void)hipFree(g->delta[i]);
+        c->ext_accum = nullptr;
+        c->group = nullptr;
+    }
+    delete g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_group_create(int n, PtContext* const* members, PtGroup** out) {
+    if (!out) return PT_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n <= 0 || n > 64 || !members) return PT_ERR_INVALID_ARG;
+    try {
+        for (int i = 0; i < n; i++) {
+            PtContext* c = members[i];
+            if (!c) return PT_ERR_INVALID_ARG;
+            if (c->device == PT_DEVICE_NONE || !c->built || c->width <= 0) return fail(c, PT_ERR_NOT_READY, "a group member needs a GPU, a built scene and a resolution");
+            if (c->group) return fail(c, PT_ERR_INVALID_ARG, "the context is a member of a group already");
+            if (c->width != members[0]->width || c->height != members[0]->height) return fail(c, PT_ERR_INVALID_ARG, "group members differ in resolution");
+            if (c->mesh.num_tris() != members[0]->mesh.num_tris() || c->accel != members[0]->accel) return fail(c, PT_ERR_INVALID_ARG, "group members hold different scenes");
+            for (int k = 0; k < i; k++)
+                if (members[k]->device == c->device) return fail(c, PT_ERR_INVALID_ARG, "two group members on one GPU");
+        }
+        PtGroup* g = new PtGroup();
+        g->n_floats = (size_t)members[0]->width * members[0]->height * 3;
+        g->comms.assign((size_t)n, nullptr);
+        g->delta.assign((size_t)n, nullptr);
+        std::vector<int> devices;
+        for (int i = 0; i < n; i++) {
+            g->members.push_back(members[i]);
+            devices.push_back(members[i]->device);
+            members[i]->group = g;
+            for (const HostMaterial& m : members[i]->mesh.materials) g->forks = g->forks || !(m.opacity >= 1.0f - PT_EPSILON);
+        }
+        ncclResult_t r;
+        {
+            StdoutToStderr quiet;
+            r = ncclCommInitAll(g->comms.data(), n, devices.data());
+        }
+        if (r != ncclSuccess) {
+            fail(members[0], PT_ERR_RCCL, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+            for (ncclComm_t& cm : g->comms) cm = nullptr;
+            release_group(g);
+            return PT_ERR_RCCL;
+        }
+        for (int i = 0; i < n; i++) {
+            PtContext* c = members[i];
+            if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&g->delta[i], g->n_floats * sizeof(float)) != hipSuccess) {
+                fail(members[0], PT_ERR_HIP, "pt_group_create: no memory for a per-frame buffer");
+                release_group(g);
+                return PT_ERR_HIP;
+            }
+            c->ext_accum = g->delta[i];  // from here on the member's batches accumulate into its per-frame buffer
+        }
+        *out = g;
+        int rc = pt_group_reset(g);
+        if (rc != PT_OK) { *out = nullptr; fail(members[0], rc, g->error); release_group(g); }
+        return rc;
+    } catch (...) {
+        return PT_ERR_NO_MEMORY;
+    }
+}
+
+void pt_group_destroy(PtGroup* g) {
+    if (g) release_group(g);
+}
+
+const char* pt_group_last_error(PtGroup* g) { return g ? g->error.c_str() : "null group"; }
+
+int pt_group_reset(PtGroup* g) {
+    if (!g) return PT_ERR_INVALID_ARG;
+    for (size_t i = 0; i < g->members.size(); i++) {
+        PtContext* c = g->members[i];
+        int rc = pt_reset(c);  // per-frame buffer, frame buffer, total samples
+        if (rc != PT_OK) return gfail(g, rc, c->error);
+        if (i == 0) PT_GHIP(g, launch_clear(cfg_of(c), c->d_accum.ptr, g->n_floats));
+    }
+    return PT_OK;
+}
+
+int pt_group_render(PtGroup* g, int spp) {
+    if (!g || spp <= 0) return gfail(g, PT_ERR_INVALID_ARG, "pt_group_render: bad arguments");
+    try {
+        const int n = (int)g->members.size();
+        for (int i = 0; i < n; i++) {
+            PtContext* c = g->members[i];
+            PT_GHIP(g, hipSetDevice(c->device));
+            PT_GHIP(g, launch_clear(cfg_of(c), g->delta[i], g->n_floats));
+            int first, count;
+            sample_share(spp, n, i, first, count);
+            int rc = render_range(c, spp, first, count);
+            if (rc != PT_OK) return gfail(g, rc, c->error);
+        }
+        // A batch whose ray queues overflowed (forking paths) adds nothing until it is rendered again at a synchronisation;
+        // that has to happen before the frame's buffer enters the reduce.  Scenes without translucent surfaces cannot
+        // overflow and stay asynchronous.
+        if (g->forks) {
+            for (PtContext* c : g->members) {
+                int rc = settle(c);
+                if (rc != PT_OK) return gfail(g, rc, c->error);
+            }
+        }
+        // one reduce per frame onto the root, each rank's call on the stream its accumulate kernels ran on
+        PT_GNCCL(g, ncclGroupStart());
+        for (int i = 0; i < n; i++) {
+            const ncclResult_t r = ncclReduce(g->delta[i], g->delta[i], g->n_floats, ncclFloat, ncclSum, 0, g->comms[i], g->members[i]->stream);
+            if (r != ncclSuccess) { (void)ncclGroupEnd(); return gfail(g, PT_ERR_RCCL, std::string("ncclReduce: ") + ncclGetErrorString(r)); }
+        }
+        PT_GNCCL(g, ncclGroupEnd());
+        PtContext* root = g->members[0];
+        PT_GHIP(g, hipSetDevice(root->device));
+        PT_GHIP(g, launch_add(cfg_of(root), root->d_accum.ptr, g->delta[0], g->n_floats));
+        PT_GHIP(g, launch_resolve(cfg_of(root), root->d_accum.ptr, root->d_frame.ptr, root->width * root->height, root->total_samples));
+        g->frames++;
+        return PT_OK;
+    } catch (...) {
+        return gfail(g, PT_ERR_NO_MEMORY, "pt_group_render: exception");
+    }
+}
+
+int pt_group_synchronize(PtGroup* g) {
+    if (!g) return PT_ERR_INVALID_ARG;
+    for (PtContext* c : g->members) {
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return gfail(g, PT_ERR_HIP, "pt_group_synchronize: stream wait failed");
+        drain_spans(c);
+    }
+    return PT_OK;
+}
+
+int pt_group_size(PtGroup* g) { return g ? (int)g->members.size() : PT_ERR_INVALID_ARG; }
 
 }  // extern "C"

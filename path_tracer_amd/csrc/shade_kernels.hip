@@ -167,6 +167,12 @@ __global__ void resolve_kernel(const float* __restrict__ accum, float* __restric
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) frame[i] = accum[i] / div;
 }
 
+// dst += src (the root of a multi-GPU group folds a frame's reduced samples into its accumulation buffer)
+__global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
 __global__ void clear_kernel(float* buf, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) buf[i] = 0.0f;
@@ -230,6 +236,11 @@ hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int
 
 hipError_t launch_resolve(const LaunchCfg& cfg, const float* accum, float* frame, int n_pixels, int total_samples) {
     hipLaunchKernelGGL(resolve_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, accum, frame, (size_t)n_pixels * 3, total_samples);
+    return hipGetLastError();
+}
+
+hipError_t launch_add(const LaunchCfg& cfg, float* dst, const float* src, size_t n) {
+    hipLaunchKernelGGL(add_kernel, dim3(cfg.blocks), dim3(256), 0, cfg.stream, dst, src, n);
     return hipGetLastError();
 }
 

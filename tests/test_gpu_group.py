@@ -1,0 +1,117 @@
+"""The multi-GPU path of the C++ host (pt_group_*: sample split over the GPUs of one process, one RCCL ncclReduce per
+frame onto the first member) on the one GPU a test box has: a group of ONE member goes through the same code --
+per-frame buffer, ncclCommInitAll, ncclReduce on the member's stream, fold into the accumulation, resolve -- and must
+give the single-context image.  (Scaling over several GPUs cannot be measured here; the split itself is covered by the
+sample-split tests of test_gpu_image_parity.py and, over processes, by test_distributed_gloo.py.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import path_tracer_amd as pta
+from common import load_gpu_scene, scene_path
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_group_rejects_what_cannot_render():
+    import ctypes
+    L = pta.lib()
+    g = ctypes.c_void_p()
+    assert L.pt_group_create(0, None, ctypes.byref(g)) == pta.ERR_INVALID_ARG
+    h = ctypes.c_void_p()
+    assert L.pt_create(pta.DEVICE_NONE, ctypes.byref(h)) == pta.PT_OK
+    arr = (ctypes.c_void_p * 1)(h)
+    assert L.pt_group_create(1, arr, ctypes.byref(g)) == pta.ERR_NOT_READY and not g.value
+    assert L.pt_group_render(None, 1) == pta.ERR_INVALID_ARG
+    L.pt_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obj,accel,env", [("cornellbox.obj", pta.BVH, None), ("cornellbox-glass.obj", pta.KD, "probe_64.hdr")])
+def test_group_of_one_is_the_single_context_image(gpu_device, obj, accel, env):
+    W, H, SPP = 160, 120, 6
+    plain = load_gpu_scene(obj, accel, env=env)
+    plain.set_resolution(W, H)
+    member = load_gpu_scene(obj, accel, env=env)
+    member.set_resolution(W, H)
+    group = pta.Group([member])
+    plain.pathtrace(SPP)
+    group.pathtrace(SPP)
+    group.synchronize()
+    # first frame: the per-frame buffer is summed from zero exactly like the accumulation buffer of the plain context
+    assert np.array_equal(member.frame_buffer(), plain.frame_buffer())
+    assert np.array_equal(member.accumulation_buffer(), plain.accumulation_buffer())
+    for _ in range(3):
+        plain.pathtrace(SPP)
+        group.pathtrace(SPP)
+    # later frames add a frame's sum to the accumulation in one addition instead of sample by sample
+    assert member.total_samples() == plain.total_samples() == 4 * SPP
+    assert np.allclose(member.frame_buffer(), plain.frame_buffer(), rtol=2e-6, atol=1e-7)
+    assert member.counters()[pta.CNT_RAYS] == plain.counters()[pta.CNT_RAYS]
+    group.reset()
+    assert member.total_samples() == 0 and not member.frame_buffer().any() and not member.accumulation_buffer().any()
+    group.pathtrace(SPP)
+    plain.reset()
+    plain.pathtrace(SPP)
+    assert np.array_equal(member.frame_buffer(), plain.frame_buffer())
+    group.close()
+    # out of the group the context renders by itself again
+    member.reset()
+    member.pathtrace(SPP)
+    assert np.array_equal(member.frame_buffer(), plain.frame_buffer())
+    member.close()
+    plain.close()
+
+
+@pytest.mark.gpu
+def test_group_completes_overflowed_batches_before_the_reduce(gpu_device):
+    """Translucent surfaces everywhere and 2x queues: batches overflow, add nothing at first and are rendered again
+    at a synchronisation.  The group has to do that before the frame's buffer enters the reduce, or samples are lost."""
+    def scene(factor):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        mats = s.materials()
+        for m in mats:
+            m.opacity = 0.5
+        s.set_materials(mats)
+        s.pre_calc(pta.BVH)
+        s.set_option(pta.OPT_QUEUE_FACTOR, factor)
+        s.set_option(pta.OPT_MAX_BATCH, 64 * 48 * 8)
+        s.set_resolution(64, 48)
+        return s
+
+    ref = scene(64)
+    for _ in range(2):
+        ref.pathtrace(8)
+    member = scene(2)
+    group = pta.Group([member])
+    for _ in range(2):
+        group.pathtrace(8)
+    group.synchronize()
+    c = member.counters()
+    assert c[pta.CNT_REPAIRED] > 0 and c[pta.CNT_SAMPLES] == 64 * 48 * 16
+    assert np.allclose(member.accumulation_buffer(), ref.accumulation_buffer(), rtol=2e-4, atol=1e-5)
+    group.close()
+    member.close()
+    ref.close()
+
+
+@pytest.mark.gpu
+def test_cli_gpus_option_keeps_the_protocol_and_the_image(gpu_device, tmp_path):
+    exe = os.path.join(ROOT, "path_tracer_amd", "CS488")
+    outs = []
+    for extra in ([], ["--gpus", "1"]):
+        pfm = str(tmp_path / ("f%d.pfm" % len(outs)))
+        r = subprocess.run([exe, scene_path("cornellbox.obj"), "--accel", "bvh", "--frames", "3", "--spp", "4", "--width", "96", "--height", "72",
+                            "--out", pfm, "--stats"] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.splitlines()
+        assert lines[0].startswith("Loading") and "Building BVH..." in lines and "Done." in lines
+        k = lines.index("Done.")
+        assert [lines[k + 1 + 2 * i] for i in range(3)] == ["4", "8", "12"]   # totalSamples, then seconds, per frame
+        assert all(float(lines[k + 2 + 2 * i]) > 0 for i in range(3))
+        assert "Mrays/s" in r.stderr
+        raw = open(pfm, "rb").read()
+        outs.append(np.frombuffer(raw[-96 * 72 * 12:], np.float32))
+    assert np.allclose(outs[0], outs[1], rtol=2e-6, atol=1e-7)
