@@ -4,12 +4,13 @@ kernel trace of the same program.  usage: pmc_cache.py <pmc_dir> [<pmc_dir> ...]
 
 Per kernel and per launch:
   L2 (TCC, summed over the XCDs' channels): requests, hits, misses, hit rate = HIT / (HIT + MISS), and the
-     request rate against the L2's peak.  A TCC request moves at most one 128-byte line; the byte figure is
-     requests x 128 B and therefore an upper bound (a 64-byte node fetch is one request as well).
+     request rate against the measured ceiling for random 64-byte fetches (130 G requests/s, see below).  A TCC
+     request moves at most one 128-byte line; the byte figure is requests x 128 B and therefore an upper bound
+     (a 64-byte node fetch is one request as well).
   L1 (TCP, summed over the CUs): cache accesses (tag look-ups: one per 64-byte-wide piece of a wave's load, so a
      16-byte-per-lane load whose 64 lanes point at 64 different nodes costs 64 of them), the read and write
-     requests L1 sent on to L2, L1's hit rate = 1 - TCC read requests / reads, and the access rate against one
-     access per clock and CU (64 B x 256 CUs x 2.4 GHz = 39.3 TB/s).
+     requests L1 sent on to L2, L1's hit rate = 1 - TCC read requests / reads, and the access rate against the
+     measured ceiling (820 G accesses/s).
   HBM (FETCH_SIZE / WRITE_SIZE, KiB; the read side doubled as gfx950 needs for wide coalesced reads).
 Counters absent from the passes are left out of the output.
 """
@@ -21,7 +22,12 @@ import os
 from collections import defaultdict
 
 L2_PEAK_GBS = 34500.0
-L1_PEAK_GBS = 256 * 64 * 2.4  # 256 CUs x one 64-byte access per clock x 2.4 GHz = 39 322 GB/s
+# Ceilings of the cache hierarchy for RANDOM 64-byte fetches (what a tree walk does), measured with
+# tools/node_fetch_probe.hip on the same chip (profiles/r02_node_fetch_probe.txt): chip-wide, the vector L1s sustain
+# 820 G tag accesses/s and the L2s 130 G requests/s (= 8.3 TB/s of 64-byte nodes), whether a node is fetched by one lane
+# as four 16-byte loads or by four lanes as one load each.
+L1_PEAK_ACCESSES_PER_US = 820000.0
+L2_PEAK_REQUESTS_PER_US = 130000.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -55,7 +61,7 @@ def main():
             if k:
                 dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
                 nl[k] += 1
-    out = {"note": a.note, "l1_peak_GBs": L1_PEAK_GBS, "l2_peak_GBs": L2_PEAK_GBS, "hbm_peak_GBs": HBM_PEAK_GBS, "kernels": {}}
+    out = {"note": a.note, "l1_peak_accesses_per_us": L1_PEAK_ACCESSES_PER_US, "l2_peak_requests_per_us": L2_PEAK_REQUESTS_PER_US, "l2_peak_GBs": L2_PEAK_GBS, "hbm_peak_GBs": HBM_PEAK_GBS, "kernels": {}}
     for k in sorted(tot):
         per = {c: tot[k][c] / max(len(disp[k][c]), 1) for c in tot[k]}
         sec = dur[k] / max(nl[k], 1)
@@ -68,14 +74,14 @@ def main():
             e["l2_GBs_upper_bound"] = per["TCC_REQ_sum"] * 128.0 / sec * 1e-9
             e["l2_frac_of_peak_upper_bound"] = e["l2_GBs_upper_bound"] / L2_PEAK_GBS
             e["l2_requests_per_us"] = per["TCC_REQ_sum"] / sec * 1e-6
+            e["l2_request_frac_of_peak"] = e["l2_requests_per_us"] / L2_PEAK_REQUESTS_PER_US
         acc, rd = per.get("TCP_TOTAL_CACHE_ACCESSES_sum"), per.get("TCP_TCC_READ_REQ_sum")
         tr = per.get("TCP_TOTAL_READ_sum")
         if tr and rd is not None:
             e["l1_read_hit_rate"] = max(0.0, 1.0 - rd / tr)
         if acc is not None and sec > 0:
             e["l1_accesses_per_us"] = acc / sec * 1e-6
-            e["l1_GBs_at_64B_per_access"] = acc * 64.0 / sec * 1e-9
-            e["l1_frac_of_peak"] = e["l1_GBs_at_64B_per_access"] / L1_PEAK_GBS
+            e["l1_frac_of_peak"] = e["l1_accesses_per_us"] / L1_PEAK_ACCESSES_PER_US
         f_kib, w_kib = per.get("FETCH_SIZE"), per.get("WRITE_SIZE")
         if f_kib is not None or w_kib is not None:
             hbm = (f_kib or 0.0) * 1024 * 2.0 + (w_kib or 0.0) * 1024
