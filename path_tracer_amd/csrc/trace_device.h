@@ -280,6 +280,12 @@ enum { LEAF_BURST = 4 };
 // A lane's `cur`: >= 0 interior node, < 0 leaf (~offset of its first record), NO_RAY = no ray.
 enum : int { NO_RAY = INT_MIN };
 
+// Nodes and records staged in LDS are 64 bytes each but stored 80 bytes apart (five float4): with a stride of 64
+// bytes every node's quarter p would start at one of only four bank positions, so lanes of one ds_read_b128 that read
+// different nodes would collide four to one and worse; 20 dwords apart, sixteen consecutive nodes start at sixteen
+// different multiples of four banks.
+enum { LDS_ITEM_F4 = 5 };
+
 // ALL_LDS: every interior node and every (leaf-ordered) intersection record is staged in LDS --
 // small scenes -- so neither the walk nor the leaf phase has a global-memory path.
 enum { LDS_RECORDS_MAX = 256, LDS_REFS_MAX = 2048 };
@@ -289,8 +295,8 @@ inline bool fits_lds(const SceneGpu& sc) {
     return sc.lds_nodes >= sc.n_nodes && sc.n_records <= LDS_RECORDS_MAX && (sc.leaf_inline || sc.n_refs <= LDS_REFS_MAX);
 }
 inline size_t dynamic_lds_bytes(const SceneGpu& sc) {
-    size_t b = (size_t)sc.lds_nodes * 64;
-    if (fits_lds(sc)) b += (size_t)sc.n_records * 64 + (sc.leaf_inline ? 0 : (size_t)sc.n_refs * 4);
+    size_t b = (size_t)sc.lds_nodes * (16 * LDS_ITEM_F4);
+    if (fits_lds(sc)) b += (size_t)sc.n_records * (16 * LDS_ITEM_F4) + (sc.leaf_inline ? 0 : (size_t)sc.n_refs * 4);
     return b;
 }
 // LDS a workgroup needs for the walk: the staged nodes (and records), four counters, the stacks.
@@ -307,12 +313,12 @@ struct TraceLds {
 template <bool ALL_LDS>
 __device__ __forceinline__ void stage_tree(const SceneGpu& sc, float4* lds_nodes) {
     const int staged = sc.lds_nodes;
-    for (int k = threadIdx.x; k < staged * 4; k += blockDim.x) lds_nodes[k] = sc.nodes[k];
-    float4* lds_records = lds_nodes + 4 * staged;
+    for (int k = threadIdx.x; k < staged * 4; k += blockDim.x) lds_nodes[(k >> 2) * LDS_ITEM_F4 + (k & 3)] = sc.nodes[k];
+    float4* lds_records = lds_nodes + LDS_ITEM_F4 * staged;
     if (ALL_LDS) {
-        for (int k = threadIdx.x; k < sc.n_records * 4; k += blockDim.x) lds_records[k] = sc.isect[k];
+        for (int k = threadIdx.x; k < sc.n_records * 4; k += blockDim.x) lds_records[(k >> 2) * LDS_ITEM_F4 + (k & 3)] = sc.isect[k];
         if (!sc.leaf_inline) {  // leaves as index lists behind the records
-            int* lds_refs = reinterpret_cast<int*>(lds_records + 4 * sc.n_records);
+            int* lds_refs = reinterpret_cast<int*>(lds_records + LDS_ITEM_F4 * sc.n_records);
             for (int k = threadIdx.x; k < sc.n_refs; k += blockDim.x) lds_refs[k] = sc.refs[k];
         }
     }
@@ -332,8 +338,8 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     float* const s_stack_t = lds.stack_t;
     const int blk = blockIdx.x;
     const int staged = sc.lds_nodes;
-    float4* const lds_records = lds_nodes + 4 * staged;
-    const int* const lds_refs = reinterpret_cast<const int*>(lds_records + 4 * sc.n_records);
+    float4* const lds_records = lds_nodes + LDS_ITEM_F4 * staged;
+    const int* const lds_refs = reinterpret_cast<const int*>(lds_records + LDS_ITEM_F4 * sc.n_records);
     if (threadIdx.x < 6) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
@@ -449,7 +455,8 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             if (cur >= 0) {
                 float4 q0, q1, q2, q3;
                 if (ALL_LDS || cur < staged) {
-                    q0 = lds_nodes[4 * cur]; q1 = lds_nodes[4 * cur + 1]; q2 = lds_nodes[4 * cur + 2]; q3 = lds_nodes[4 * cur + 3];
+                    const float4* np = lds_nodes + LDS_ITEM_F4 * cur;
+                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
                 } else {
                     const float4* np = sc.nodes + 4 * (size_t)cur;
                     q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
@@ -493,7 +500,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     const int k = valid ? leaf_k + j : leaf_n - 1;
                     if (COUNT) n_tri += valid ? 1 : 0;
                     if (COUNT) n_wave_rounds += lane == __ffsll((long long)lane_mask(true)) - 1 ? 1 : 0;
-                    const float4* rec = ALL_LDS ? lds_records + 4 * lds_refs[off + 1 + k]
+                    const float4* rec = ALL_LDS ? lds_records + LDS_ITEM_F4 * lds_refs[off + 1 + k]
                                                 : sc.isect + 4 * (size_t)sc.refs[off + 1 + k];
                     triangle_round<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, valid, best);
                 }
@@ -503,7 +510,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     const bool valid = j == 0 || leaf_k + j < leaf_n;
                     if (j > 0 && lane_mask(valid) == 0ull) break;
                     const int k = valid ? leaf_k + j : leaf_n - 1;
-                    const float4* rec = ALL_LDS ? lds_records + 4 * (off + k) : sc.isect + 4 * (size_t)(off + k);
+                    const float4* rec = ALL_LDS ? lds_records + LDS_ITEM_F4 * (off + k) : sc.isect + 4 * (size_t)(off + k);
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                     if (j == 0) leaf_n = leaf_k == 0 ? __float_as_int(r1.w) : leaf_n;  // a leaf's first record carries its size
                     if (COUNT) n_tri += valid ? 1 : 0;
