@@ -66,6 +66,7 @@ struct SceneGpu {
     int n_refs;       // entries of `refs` (leaf_inline = 0)
     int shared_origin; // 1: every ray of the launch starts at ray_o[0] (camera rays are stored as directions only)
     int shading_kind; // which instantiation of the shading code the scene needs (SHADE_ALL / _LAMBERTIAN / _PLAIN / _GLASS / _METAL)
+    int fixed_radiance; // 1: paths fork (translucent surfaces), per-sample radiance is summed in 64-bit fixed point (two float4 per sample)
     int planes_ok;  // every box coordinate is 0 or at least 1e-17 in magnitude (reciprocal slab form allowed)
 };
 
@@ -97,6 +98,7 @@ struct BatchGpu {
     int cap_block;     // queue entries owned by one workgroup
     int slots_block;   // most camera samples one workgroup generates
     int deal_shift;    // rotation of the run -> workgroup assignment per dealing round
+    int fixed_radiance;  // copy of SceneGpu::fixed_radiance for the kernels that see only the batch
     const uint64_t* keys;  // sampler key of each of the batch's `chunk` sample indices
     int* overflow;     // the batch's flag: cleared by raygen, set by a workgroup whose queue region ran
                        // full, read by accumulate (a flagged batch adds nothing and is rendered again

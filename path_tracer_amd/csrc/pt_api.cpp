@@ -430,6 +430,9 @@ int flatten_and_upload(PtContext* c) {
         if (hm2.textured || !(hm2.opacity >= 1.0f - PT_EPSILON)) plain = false;
     }
     // SHADE_ALL 0 / SHADE_LAMBERTIAN 1 / SHADE_PLAIN 2 / SHADE_GLASS 3 / SHADE_METAL 4 of shade_device.h
+    s.fixed_radiance = 0;
+    for (const HostMaterial& hm2 : m.materials)
+        if (!(hm2.opacity >= 1.0f - PT_EPSILON)) s.fixed_radiance = 1;  // the alpha fork of src/cs488.h:2038
     s.shading_kind = (other || (metal && glass)) ? 0 : (glass ? 3 : (metal ? 4 : (plain ? 2 : 1)));
     choose_lds_nodes(c);
     s.planes_ok = 1;
@@ -509,7 +512,7 @@ int ensure_lane(PtContext* c, Lane& ln, size_t batch) {
         PT_HIP(c, ln.q_beta[k].ensure(cap));
     }
     PT_HIP(c, ln.d_hit.ensure(cap));
-    PT_HIP(c, ln.d_sample_rad.ensure(batch));
+    PT_HIP(c, ln.d_sample_rad.ensure(2 * batch));  // two records per sample where radiance is summed in fixed point
     ln.batch_alloc = batch;
     return PT_OK;
 }
@@ -601,6 +604,7 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     BatchGpu b;
     b.pixel0 = pixel0; b.n_pixels = n_pixels; b.chunk = chunk; b.sample0 = sample0;
     b.seed = c->seed;
+    b.fixed_radiance = c->scene.fixed_radiance;
     b.n_slots = n_pixels * chunk;
     Lane& ln = c->lanes[c->batch_seq % (uint64_t)c->n_lanes];
     const bool own_stream = c->n_lanes > 1;
@@ -1354,6 +1358,7 @@ int pt_camera_samples(PtContext* c, int sample, float* rays6) {
     camera_of(c, cam);
     BatchGpu b;
     b.pixel0 = 0; b.n_pixels = (int)n_pixels; b.chunk = 1; b.sample0 = sample; b.seed = c->seed; b.n_slots = (int)n_pixels;
+    b.fixed_radiance = c->scene.fixed_radiance;
     shape_batch(c, ln, c->n_lanes > 1, b);
     PT_HIP(c, ln.d_keys.ensure(1024));
     PT_HIP(c, ln.d_eye.ensure(1));

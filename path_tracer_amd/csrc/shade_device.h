@@ -107,11 +107,51 @@ __device__ __forceinline__ void wave_reserve(bool e0, bool e1, int* lds_counter,
     idx1 = base + c0 + __popcll(m1 & below);
 }
 
-__device__ __forceinline__ void add_radiance(float4* sample_rad, int slot, vec3 v) {
-    float* p = reinterpret_cast<float*>(sample_rad + slot);
-    atomicAdd(p + 0, v.x);
-    atomicAdd(p + 1, v.y);
-    atomicAdd(p + 2, v.z);
+// Adds a path's contribution to its camera sample.  A scene without translucent surfaces has one path per sample,
+// whose contributions arrive level by level: float atomics, always in the same order.  Where paths fork
+// (src/cs488.h:2038-2044) several paths share a sample and the order of their additions depends on timing, so such a
+// scene (sc.fixed_radiance) sums in 64-bit fixed point instead -- units of 2^-32, exact and therefore independent of
+// the order; the image is then the same bits run after run, as the reference's is with one thread.  A record is two
+// float4 there: three sums and a word of flags for what fixed point cannot hold (bit 0: NaN; bits 1-3 / 4-6: +inf /
+// -inf or beyond +-2^30 in r, g, b), which accumulate_kernel turns back into the float it stands for.
+enum { RAD_NAN = 1, RAD_POS_INF = 2, RAD_NEG_INF = 16 };
+__device__ __forceinline__ void add_radiance(const SceneGpu& sc, float4* sample_rad, int slot, vec3 v) {
+    if (!sc.fixed_radiance) {
+        float* p = reinterpret_cast<float*>(sample_rad + slot);
+        atomicAdd(p + 0, v.x);
+        atomicAdd(p + 1, v.y);
+        atomicAdd(p + 2, v.z);
+        return;
+    }
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(sample_rad + 2 * (size_t)slot);
+    const float c[3] = {v.x, v.y, v.z};
+    unsigned int flags = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (fabsf(c[k]) < 1073741824.0f) {  // false for NaN
+            const long long q = __float2ll_rn(c[k] * 4294967296.0f);
+            if (q != 0) atomicAdd(p + k, (unsigned long long)q);
+        } else {
+            flags |= isnan(c[k]) ? (unsigned int)RAD_NAN : ((c[k] > 0.0f ? (unsigned int)RAD_POS_INF : (unsigned int)RAD_NEG_INF) << k);
+        }
+    }
+    if (flags) atomicOr(reinterpret_cast<unsigned int*>(p + 3), flags);
+}
+
+// The float a fixed-point record stands for (see add_radiance).
+__device__ __forceinline__ float4 radiance_of_fixed(const float4& lo, const float4& hi) {
+    const long long r = (long long)(((unsigned long long)__float_as_uint(lo.y) << 32) | __float_as_uint(lo.x));
+    const long long g = (long long)(((unsigned long long)__float_as_uint(lo.w) << 32) | __float_as_uint(lo.z));
+    const long long b = (long long)(((unsigned long long)__float_as_uint(hi.y) << 32) | __float_as_uint(hi.x));
+    const unsigned int flags = __float_as_uint(hi.z);
+    float out[3] = {(float)((double)r * (1.0 / 4294967296.0)), (float)((double)g * (1.0 / 4294967296.0)), (float)((double)b * (1.0 / 4294967296.0))};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const bool pos = (flags & ((unsigned int)RAD_POS_INF << k)) != 0, neg = (flags & ((unsigned int)RAD_NEG_INF << k)) != 0;
+        if (pos || neg) out[k] = pos && neg ? NAN : (pos ? INFINITY : -INFINITY);
+    }
+    if (flags & RAD_NAN) out[0] = NAN;
+    return make_float4(out[0], out[1], out[2], 0.0f);
 }
 
 __device__ __forceinline__ bool finite3(vec3 v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
@@ -280,10 +320,10 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
             if (tri < 0) {
                 // miss: environment radiance (zero without a probe; the product keeps a NaN alive)
                 if (KIND == SHADE_PLAIN) {  // no environment: radiance zero, times a throughput that may be NaN
-                    if (!finite3(beta)) add_radiance(sample_rad, slot, beta * 0.0f);
+                    if (!finite3(beta)) add_radiance(sc, sample_rad, slot, beta * 0.0f);
                 } else {
                     const vec3 e = env_lookup(sc, d) * h.z;  // miss record: h.z = the ray's miss scale
-                    if (sc.env_h != 0 || !finite3(beta)) add_radiance(sample_rad, slot, beta * e);
+                    if (sc.env_h != 0 || !finite3(beta)) add_radiance(sc, sample_rad, slot, beta * e);
                 }
             } else if (level > max_level) {
                 ended = true;
@@ -342,7 +382,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                         const float p = div_by_recip(ct, PT_PI, 1.0f / PT_PI);
                         const bool translucent = KIND != SHADE_PLAIN && opacity < 1.0f - PT_EPSILON;
                         const vec3 weight = translucent ? beta * opacity : beta;
-                        if (Ke.x != 0.0f || Ke.y != 0.0f || Ke.z != 0.0f) add_radiance(sample_rad, slot, weight * Ke);
+                        if (Ke.x != 0.0f || Ke.y != 0.0f || Ke.z != 0.0f) add_radiance(sc, sample_rad, slot, weight * Ke);
                         emit0 = true;
                         o0 = P + PT_EPSILON * N;
                         d0 = wo;
@@ -396,7 +436,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                     }
                 } else if (KIND == SHADE_ALL) {
                     // unknown material type: the reference's error colour (src/cs488.h:2170)
-                    add_radiance(sample_rad, slot, beta * v3(100.0f, 0.0f, 100.0f));
+                    add_radiance(sc, sample_rad, slot, beta * v3(100.0f, 0.0f, 100.0f));
                 }
 
                 // random-number bookkeeping of the children: a fork doubles the path id
@@ -408,7 +448,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                     bits0 = (pid << 8) | (rng.dim & 0xffu);
                 }
             }
-            if (ended && !finite3(beta)) add_radiance(sample_rad, slot, v3(NAN));
+            if (ended && !finite3(beta)) add_radiance(sc, sample_rad, slot, v3(NAN));
         }
 
         int k0, k1;

@@ -56,7 +56,12 @@ __global__ __launch_bounds__(256) void raygen_kernel(CameraGpu cam, BatchGpu b, 
         // a camera ray is its direction: origin (the eye), miss scale (1), throughput (1, 1, 1) and sample slot
         // (a function of the position in the region) are known to the stages that follow
         out.ray_d[region + j] = make_float4(d.x, d.y, d.z, __uint_as_float((1u << 8) | rng.dim));
-        sample_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (b.fixed_radiance) {
+            sample_rad[2 * (size_t)slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            sample_rad[2 * (size_t)slot + 1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            sample_rad[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
     }
 }
 
@@ -114,12 +119,16 @@ __global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float
     for (int pl = blockIdx.x * blockDim.x + threadIdx.x; pl < b.n_pixels; pl += stride) {
         float* dst = accum + 3 * (size_t)(b.pixel0 + pl);
         float ax = dst[0], ay = dst[1], az = dst[2];
-        const float4* src = sample_rad + (size_t)pl * b.chunk;
+        const float4* src = sample_rad + (size_t)pl * b.chunk * (b.fixed_radiance ? 2 : 1);
         // four loads in flight per lane (one 64-byte sector), summed in sample order
         for (int k0 = 0; k0 < b.chunk; k0 += 4) {
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = k0 + u < b.chunk ? src[k0 + u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int u = 0; u < 4; u++) {
+                if (k0 + u >= b.chunk) v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                else if (b.fixed_radiance) v[u] = radiance_of_fixed(src[2 * (k0 + u)], src[2 * (k0 + u) + 1]);
+                else v[u] = src[k0 + u];
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (k0 + u >= b.chunk) break;

@@ -237,3 +237,31 @@ def test_small_and_odd_shapes(gpu_device):
     assert not s.accumulation_buffer().any()
     c = s.counters()
     assert c[pta.CNT_RAYS] == 16 * 16 * 4 and c[pta.CNT_HITS] == 0
+
+
+def test_translucent_scenes_render_the_same_bits_every_time(gpu_device):
+    """Where paths fork (Op < 1, src/cs488.h:2038-2044) several paths add to one camera sample.  Their sums are kept in
+    fixed point, so the order in which they arrive cannot show: two renders give the same bits, as the reference does
+    with one thread, and so does the same frame cut into smaller batches."""
+    import path_tracer_amd as pta
+
+    def render(max_batch=None, streams=None):
+        s = load_gpu_scene("cornellbox-alpha.obj", orc.KD, env="probe_64.hdr")
+        if max_batch:
+            s.set_option(pta.OPT_MAX_BATCH, max_batch)
+        if streams:
+            s.set_option(pta.OPT_STREAMS, streams)
+        s.set_resolution(160, 120)
+        for _ in range(3):
+            s.pathtrace(6)
+        img, acc, c = s.frame_buffer(), s.accumulation_buffer(), s.counters()
+        s.close()
+        return img, acc, c
+
+    a_img, a_acc, a_c = render()
+    b_img, b_acc, b_c = render()
+    assert np.array_equal(a_img, b_img) and np.array_equal(a_acc, b_acc)
+    assert a_c[pta.CNT_RAYS] == b_c[pta.CNT_RAYS] and a_c[pta.CNT_NAN_SAMPLES] == 0
+    c_img, c_acc, c_c = render(max_batch=160 * 120 * 2, streams=1)
+    assert np.array_equal(a_acc, c_acc) and c_c[pta.CNT_RAYS] == a_c[pta.CNT_RAYS]
+    assert np.isfinite(a_img).all() and a_img.mean() > 0.05
