@@ -1,1 +1,1 @@
-cd $GRAFT_REPO_ROOT && timeout -k 10 300 python tools/batch_size_probe.py cornellbox.obj bvh && timeout -k 10 300 python tools/batch_size_probe.py cornellbox.obj kd
+bash tools/gpu_sweep.sh "--no-sponza --no-pmc --no-kd" --blocks-per-cu 3 4 5 6 8 && bash tools/gpu_sweep.sh "--no-sponza --no-pmc --no-kd" --tail-level 3 4 5 6 7
