@@ -136,6 +136,7 @@ enum {
 /* Replaces the static construction of globalScene (src/cs488.h:1900).  `device` is a HIP device
  * ordinal.  Fails with PT_ERR_HIP when no GPU is usable: there is no CPU fallback. */
 int pt_create(int device, PtContext** out);
+/* (A member of a group is left alone: destroy the group first.) */
 void pt_destroy(PtContext* ctx);
 const char* pt_last_error(PtContext* ctx);
 /* Use an existing HIP stream (hipStream_t as void*) for every launch instead of the context's own. */

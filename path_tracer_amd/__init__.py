@@ -126,6 +126,9 @@ class Scene:
         return rc
 
     def close(self):
+        group = getattr(self, "_group", None)
+        if group is not None:  # a member of a group is destroyed after the group
+            group.close()
         if getattr(self, "h", None):
             self.L.pt_destroy(self.h)
             self.h = None
@@ -359,6 +362,8 @@ class Group:
         rc = self.L.pt_group_create(len(self.scenes), arr, C.byref(self.h))
         if rc != PT_OK:
             raise PtError(rc, (self.L.pt_last_error(self.scenes[0].h) or b"").decode(errors="replace") if self.scenes else "empty group")
+        for s in self.scenes:
+            s._group = self
 
     def _check(self, rc):
         if rc < 0:
@@ -378,6 +383,8 @@ class Group:
         if getattr(self, "h", None):
             self.L.pt_group_destroy(self.h)
             self.h = None
+            for s in self.scenes:
+                s._group = None
 
     def __del__(self):
         try:

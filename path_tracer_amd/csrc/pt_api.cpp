@@ -848,6 +848,7 @@ void pt_destroy(PtContext* c) {
 const char* pt_last_error(PtContext* c) { return c ? c->error.c_str() : "null context"; }
 
 int pt_set_stream(PtContext* c, void* hip_stream) {
+    if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     PT_HIP(c, hipStreamSynchronize(c->stream));
@@ -1057,6 +1058,7 @@ int pt_get_env(PtContext* c, float* rgb, int* w, int* h) {
 // ---- accelerator ----
 int pt_build(PtContext* c, int accel) {
     PT_TRY
+    if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c) return PT_ERR_INVALID_ARG;
     if (accel != PT_ACCEL_BVH && accel != PT_ACCEL_KD) return fail(c, PT_ERR_INVALID_ARG, "unknown accelerator kind");
     if (c->mesh.num_tris() == 0) return fail(c, PT_ERR_NOT_READY, "no mesh loaded");
@@ -1103,6 +1105,7 @@ int pt_set_camera(PtContext* c, const float eye[3], const float lookat[3], const
 }
 
 int pt_set_resolution(PtContext* c, int width, int height) {
+    if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c || width <= 0 || height <= 0) return fail(c, PT_ERR_INVALID_ARG, "bad resolution");
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     PT_HIP(c, hipSetDevice(c->device));
@@ -1129,6 +1132,7 @@ int pt_reset(PtContext* c) {
 // ---- hot path ----
 int pt_render(PtContext* c, int spp) {
     PT_TRY
+    if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c) return PT_ERR_INVALID_ARG;
     int rc = render_range(c, spp, 0, spp);
     if (rc != PT_OK) return rc;
@@ -1138,6 +1142,7 @@ int pt_render(PtContext* c, int spp) {
 
 int pt_render_split(PtContext* c, int spp_frame, int first, int count) {
     PT_TRY
+    if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c) return PT_ERR_INVALID_ARG;
     return render_range(c, spp_frame, first, count);
     PT_CATCH(c)
@@ -1180,6 +1185,7 @@ int pt_download(PtContext* c, int which, float* dst) {
 void* pt_accum_device_ptr(PtContext* c) { return c ? (void*)c->accum_ptr() : nullptr; }
 
 int pt_use_external_accum(PtContext* c, void* device_ptr) {
+    if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     // no wait: everything that touches the buffers is ordered on the context's stream

@@ -50,6 +50,8 @@ def test_group_of_one_is_the_single_context_image(gpu_device, obj, accel, env):
     assert member.total_samples() == plain.total_samples() == 4 * SPP
     assert np.allclose(member.frame_buffer(), plain.frame_buffer(), rtol=2e-6, atol=1e-7)
     assert member.counters()[pta.CNT_RAYS] == plain.counters()[pta.CNT_RAYS]
+    with pytest.raises(pta.PtError):  # a member is driven through the group only
+        member.pathtrace(SPP)
     group.reset()
     assert member.total_samples() == 0 and not member.frame_buffer().any() and not member.accumulation_buffer().any()
     group.pathtrace(SPP)

@@ -18,5 +18,5 @@ for f in ("bench_$T","bench_coll_$T","bench_coll_alpha_$T"):
     r=d["roofline"]
     print(f, "Mrays/s %.0f ms %.3f bound %s frac %.3f fracs %s traffic %s" % (d["value"], d["ms_per_step"], r["bound"], r["frac"], r["fractions"], r["traffic"]))
     if "sponza" in d: print(" sponza", {k:(v["Mrays/s"], v["trace_kernel_alone"]["fp32_frac"]) for k,v in d["sponza"].items() if isinstance(v,dict)})
-    if "cpu_baseline" in d: print(" cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["reference_thread_rule"]["value"], d["cpu_baseline"]["host"])
+    if "cpu_baseline" in d: print(" cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["threads"], d["cpu_baseline"]["cores"], d["cpu_baseline"]["one_thread_per_core"]["value"], d["cpu_baseline"]["host"])
 PY
