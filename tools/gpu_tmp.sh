@@ -1,1 +1,1 @@
-bash tools/gpu_sweep.sh "--no-sponza --no-pmc --no-kd" --blocks-per-cu 3 4 5 6 8 && bash tools/gpu_sweep.sh "--no-sponza --no-pmc --no-kd" --tail-level 3 4 5 6 7
+bash tools/gpu_pmc_all.sh f3_cb cornellbox.obj bvh && bash tools/gpu_pmc_all.sh f3_spb sponza bvh && bash tools/gpu_pmc_all.sh f3_spk sponza kd
