@@ -109,7 +109,9 @@ def committed_counters(args, world):
     tag = None
     if is_default_workload(args, world):
         tag = "cornellbox_bvh"
-    elif args.workload == "sponza" and not args.obj and (args.width, args.height, args.spp) == (3840, 2160, 4) and world == 1:
+    elif args.workload == "sponza" and not args.obj and (args.width, args.height) == (3840, 2160) and args.spp >= 2:
+        # (a batch holds two samples per pixel at this size whatever the frame's sample count, and every rank of a
+        # sample split runs the same batches, so the per-launch rates of the committed passes apply)
         tag = "sponza_%s" % args.accel
     if tag is None:
         return None
