@@ -46,3 +46,22 @@ def test_oracle_outputs_are_the_recorded_ones(obj, accels, env, frame):
 def test_every_recorded_scene_is_checked():
     keys = {"%s/%s" % (obj, "kd" if a == mk.orc.KD else "bvh") for obj, accels, _, _ in mk.SCENES for a in accels}
     assert keys == set(RECORD["scenes"])
+
+
+def test_converged_renders_cover_every_benchmark_scene():
+    """tests/golden/oracle/converged.npz (two 4096-sample oracle renders per scene, the references of
+    tests/test_gpu_converged.py) holds exactly the scenes its generator lists, as finite 48 x 64 images; one of them is
+    recomputed at a sixteenth of the samples and must agree with the stored pair within the noise of that."""
+    import make_converged_images as cv
+    ref = mk.np.load(cv.OUT)
+    assert set(ref.files) == {"%s/%s" % (key, tag) for key, _, _, _ in cv.SCENES for tag in "ab"}
+    for name in ref.files:
+        assert ref[name].shape == (cv.H, cv.W, 3) and mk.np.isfinite(ref[name]).all() and ref[name].mean() > 0.05, name
+    o = cv.load_oracle_scene("cornellbox.obj", mk.orc.BVH)
+    o.reset(cv.W, cv.H)
+    o.render(spp=64, frames=4, threads=cv.THREADS, state=cv.SEEDS[0])
+    quick = o.image()
+    a, b = ref["cornellbox/a"], ref["cornellbox/b"]
+    assert abs(quick.mean() - a.mean()) < 0.01 * a.mean()
+    floor = float(mk.np.sqrt(mk.np.mean((a - b) ** 2)))
+    assert float(mk.np.sqrt(mk.np.mean((quick - a) ** 2))) < 4.0 * floor  # 1/16 of the samples: about 2.9 x the pair's RMSE
