@@ -72,7 +72,9 @@ enum {
     PT_OPT_TRAVERSAL = 8,     /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab and triangle
                                  quotients from an exact reciprocal plus one exact correction step instead of the
                                  division sequence (default on); bit 2: refill a wave only when all its lanes are idle
-                                 (measurement); bits 4..7: k of the node phase's early-leave rule (leave when the lanes
+                                 (measurement); bit 3: every workgroup traces the rays of its own queue region, also where the default
+                                 lets the workgroups draw chunks of 64 rays from shared pools (pt_trace_batch, and
+                                 rendering with PT_OPT_STREAMS = 1); bits 4..7: k of the node phase's early-leave rule (leave when the lanes
                                  on interior nodes number less than 1/k of those waiting at a leaf; 0, the default:
                                  4 for a scene held entirely in LDS, else 1; 15 = never leave early); bits 8..14: idle
                                  lanes a wave waits for before it fetches new rays (0, the default: 32 for a scene held

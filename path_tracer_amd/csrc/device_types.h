@@ -127,11 +127,14 @@ hipError_t launch_raygen(const LaunchCfg& cfg, const CameraGpu& cam, const Batch
 // the camera rays of a one-sample-per-pixel batch, from the queue raygen wrote, in pixel order (n_pixels x 6 floats)
 hipError_t launch_gather_camera_rays(const LaunchCfg& cfg, const CameraGpu& cam, const BatchGpu& batch, const float4* ray_d,
                                      const int* qcount, float* rays6);
-// One workgroup per queue region: `grid_blocks` regions of `cap_block` entries.  With n_rays ==
-// nullptr the input is one flat array of n_fixed rays cut into consecutive regions.
+// `grid_blocks` queue regions of `cap_block` entries, traced by as many workgroups, which draw the rays from
+// shared pools: `cursors` = TRACE_POOL_INTS ints that are zero when the launch starts (the launch leaves them
+// non-zero; one cursor per pool, each in a 256-byte stretch of its own, because atomics on one cache line are
+// served one after the other).  With n_rays == nullptr the input is one flat array of n_fixed rays cut into consecutive regions.
+enum { TRACE_POOL_CURSORS = 32, TRACE_POOL_STRIDE = 64, TRACE_POOL_INTS = TRACE_POOL_CURSORS * TRACE_POOL_STRIDE };
 hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int count_tests, int fast_slab,
                         const float4* ray_o, const float4* ray_d, float4* hit, const int* n_rays, int n_fixed,
-                        int grid_blocks, int cap_block, unsigned long long* block_stats);
+                        int grid_blocks, int cap_block, int* cursors, unsigned long long* block_stats);
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
                         int* qcount_out);

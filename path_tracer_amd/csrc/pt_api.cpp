@@ -79,6 +79,7 @@ struct Lane {
     DeviceBuffer<float4> d_eye;           // origin record shared by the camera rays of the lane's batch
     DeviceBuffer<uint64_t> d_keys;        // sampler keys of the lane's batch
     DeviceBuffer<int> d_qcount;
+    DeviceBuffer<int> d_cursors;          // pool cursors of the batch's trace launches: TRACE_POOL_CURSORS per level, cleared per batch
     DeviceBuffer<unsigned long long> d_block_stats;
     size_t batch_alloc = 0;
     hipEvent_t done[2] = {nullptr, nullptr};      // the lane's kernels of a batch have been queued up to here
@@ -86,7 +87,7 @@ struct Lane {
     uint64_t uses = 0;
     void release() {
         for (int k = 0; k < 2; k++) { q_ray_o[k].release(); q_ray_d[k].release(); q_beta[k].release(); }
-        d_hit.release(); d_sample_rad.release(); d_eye.release(); d_keys.release(); d_qcount.release(); d_block_stats.release();
+        d_hit.release(); d_sample_rad.release(); d_eye.release(); d_keys.release(); d_qcount.release(); d_cursors.release(); d_block_stats.release();
         batch_alloc = 0;
     }
 };
@@ -144,6 +145,7 @@ struct PtContext {
     int lane_stream_swaps = 0;            // streams replaced by that probe
     DeviceBuffer<unsigned long long> d_totals;
     DeviceBuffer<unsigned long long> d_block_stats;  // of pt_trace_batch (the lanes have their own)
+    DeviceBuffer<int> d_cursors;          // pool cursors of pt_trace_batch's launch, cleared before each
     DeviceBuffer<int> d_batch_flags;      // FLAG_RING overflow flags, one per batch in flight
     std::vector<IssuedBatch> issued;      // batches whose flags have not been looked at yet
     uint64_t batch_seq = 0, repaired_batches = 0;
@@ -636,6 +638,7 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     const int levels = c->max_level + 2;  // levels 0 .. maxLevel+1; the last one only resolves misses
     // every stage writes every workgroup's count of the next level, so the counts need no clearing
     PT_HIP(c, ln.d_qcount.ensure(((size_t)levels + 1) * (size_t)c->blocks));
+    PT_HIP(c, ln.d_cursors.ensure((size_t)levels * TRACE_POOL_INTS));
     QueueSet q[2];
     for (int k = 0; k < 2; k++) { q[k].ray_o = ln.q_ray_o[k].ptr; q[k].ray_d = ln.q_ray_d[k].ptr; q[k].beta = ln.q_beta[k].ptr; }
     // camera rays are stored as directions only: one shared origin record, no throughputs
@@ -645,6 +648,12 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     const SceneGpu& scene = c->scene;
     SceneGpu scene0 = c->scene;
     scene0.shared_origin = 1;
+    // One batch at a time: the trace launches draw their rays from shared pools, so that every wave works until a
+    // launch's rays are used up.  With another batch in flight private regions are faster (its kernels fill what the
+    // workgroups that finish early leave; measured 15.5 against 14.9 Grays/s on the cornellbox, 12.5 against 11.1 alone).
+    const int trace_mode = c->traversal | (own_stream ? 8 : 0);
+    if ((trace_mode & 8) == 0)
+        PT_HIP(c, hipMemsetAsync(ln.d_cursors.ptr, 0, (size_t)levels * TRACE_POOL_INTS * sizeof(int), cfg.stream));
     {
         ScopedTimer tm(c, PT_TIMER_RAYGEN, cfg.stream);
         PT_HIP(c, launch_raygen(cfg, cam, b, camera_rays, ln.d_sample_rad.ptr, ln.d_qcount.ptr));
@@ -667,8 +676,9 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
         const QueueSet& out = q[(level + 1) & 1];
         {
             ScopedTimer tm(c, PT_TIMER_TRACE, cfg.stream);
-            PT_HIP(c, launch_trace(cfg, level == 0 ? scene0 : scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, in.ray_o, in.ray_d,
-                                   ln.d_hit.ptr, ln.d_qcount.ptr + (size_t)level * nb, 0, nb, b.cap_block, ln.d_block_stats.ptr));
+            PT_HIP(c, launch_trace(cfg, level == 0 ? scene0 : scene, c->accel == PT_ACCEL_KD, c->count_tests, trace_mode, in.ray_o, in.ray_d,
+                                   ln.d_hit.ptr, ln.d_qcount.ptr + (size_t)level * nb, 0, nb, b.cap_block,
+                                   ln.d_cursors.ptr + (size_t)level * TRACE_POOL_INTS, ln.d_block_stats.ptr));
         }
         {
             ScopedTimer tm(c, PT_TIMER_SHADE, cfg.stream);
@@ -805,8 +815,10 @@ int pt_create(int device, PtContext** out) {
     hipDeviceProp_t prop;
     // eight 256-lane workgroups per CU are resident at once with the kernels' register and LDS use
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) { c->cus = prop.multiProcessorCount; c->blocks = prop.multiProcessorCount * 8; }
+    if (c->blocks > TRACE_POOL_CURSORS * 64) c->blocks = TRACE_POOL_CURSORS * 64;  // the most regions one trace launch serves
     if (c->d_totals.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         c->d_batch_flags.ensure(FLAG_RING) != hipSuccess || hipMemset(c->d_batch_flags.ptr, 0, FLAG_RING * sizeof(int)) != hipSuccess ||
+        c->d_cursors.ensure(TRACE_POOL_INTS) != hipSuccess ||
         c->d_block_stats.ensure((size_t)c->blocks * DC_BLOCK_COUNT) != hipSuccess ||
         hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)) != hipSuccess) {
         pt_destroy(c);
@@ -839,7 +851,7 @@ void pt_destroy(PtContext* c) {
         }
         ln.release();
     }
-    c->d_totals.release(); c->d_block_stats.release(); c->d_batch_flags.release();
+    c->d_totals.release(); c->d_block_stats.release(); c->d_cursors.release(); c->d_batch_flags.release();
     c->tb_rays.release(); c->tb_t.release(); c->tb_bary.release(); c->tb_tri.release(); c->tb_o.release(); c->tb_d.release(); c->tb_h.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1280,10 +1292,11 @@ int pt_trace_batch(PtContext* c, int n, const float* rays6, int32_t* tri, float*
     int nb = (n + 255) / 256;
     nb = nb > c->blocks ? c->blocks : nb;
     const int cap_block = (n + nb - 1) / nb;
+    PT_HIP(c, hipMemsetAsync(c->d_cursors.ptr, 0, TRACE_POOL_INTS * sizeof(int), c->stream));
     {
         ScopedTimer tm(c, PT_TIMER_TRACE);
         PT_HIP(c, launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, d_o.ptr, d_d.ptr, d_h.ptr,
-                               nullptr, n, nb, cap_block, c->d_block_stats.ptr));
+                               nullptr, n, nb, cap_block, c->d_cursors.ptr, c->d_block_stats.ptr));
     }
     c->batch_rays += (uint64_t)n;
     PT_HIP(c, launch_unpack_hits(cfg, d_h.ptr, n, d_tri.ptr, d_t.ptr, d_bary.ptr));
@@ -1318,8 +1331,9 @@ int pt_trace_batch_static(PtContext* c, int n, const float* d_rays6, int32_t* d_
     int nb = (n + 255) / 256;
     nb = nb > c->blocks ? c->blocks : nb;
     const int cap_block = (n + nb - 1) / nb;
-    if (launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, ray_o, ray_d, hits, nullptr, n, nb, cap_block,
-                     c->d_block_stats.ptr) != hipSuccess)
+    if (hipMemsetAsync(c->d_cursors.ptr, 0, TRACE_POOL_INTS * sizeof(int), c->stream) != hipSuccess ||
+        launch_trace(cfg, c->scene, c->accel == PT_ACCEL_KD, c->count_tests, c->traversal, ray_o, ray_d, hits, nullptr, n, nb, cap_block,
+                     c->d_cursors.ptr, c->d_block_stats.ptr) != hipSuccess)
         return fail_noexcept(c, PT_ERR_HIP, "pt_trace_batch_static: launch failed");
     c->batch_rays += (uint64_t)n;
     if (launch_unpack_hits(cfg, hits, n, d_tri, d_t, d_bary2) != hipSuccess) return fail_noexcept(c, PT_ERR_HIP, "pt_trace_batch_static: launch failed");

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int 
                                                    int* __restrict__ qcount, unsigned long long* __restrict__ block_stats,
                                                    int leave_k) {
     extern __shared__ float4 lds_nodes[];
-    __shared__ __attribute__((aligned(16))) unsigned int s_stat[8];
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[PT_STAT_WORDS];
     __shared__ __attribute__((aligned(16))) int s_stack[LdsStack<KD>::ROWS * 256];
     __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LdsStack<KD>::ROWS * 256 : 4];
     __shared__ int s_out;
@@ -34,12 +34,13 @@ __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int 
     const size_t region = (size_t)blk * b.cap_block;
     if (n > 0) stage_tree<ALL_LDS>(sc, lds_nodes);  // n is the same for every thread of the workgroup
     TraceLds<KD> lds;
-    lds.nodes = lds_nodes; lds.stat = s_stat; lds.stack = s_stack; lds.stack_t = s_stack_t;
+    lds.nodes = lds_nodes; lds.stat = s_stat; lds.stack = s_stack; lds.stack_t = s_stack_t; lds.count = nullptr;
+    const RayPool no_pool = {};
     for (int level = level0; level < levels; level++) {
         if (n > 0) {
             const QueueSet& in = (level & 1) ? qb : qa;
             const QueueSet& out = (level & 1) ? qa : qb;
-            trace_region<KD, false, SLAB, true, ALL_LDS>(sc, in.ray_o, in.ray_d, hit, n, region, block_stats, leave_k, lds);
+            trace_region<KD, false, SLAB, true, ALL_LDS, false>(sc, in.ray_o, in.ray_d, hit, n, region, block_stats, leave_k, lds, no_pool);
             n = shade_region<KIND, false>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
             __syncthreads();  // s_out is rewritten by the next level's shading
         }

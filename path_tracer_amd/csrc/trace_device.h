@@ -47,6 +47,11 @@ namespace trace_dev {
 // takes an int and costs a select and a second comparison per use).
 __device__ __forceinline__ unsigned long long lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// s_waitcnt vmcnt(0): every vector-memory operation of the wave has completed.  The compiler places its own waits
+// where a loaded register is first used, on every path that may reach the use; written where the load is, the wait
+// stays off the paths that never loaded.
+__device__ __forceinline__ void wait_for_vector_memory() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 
 __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float hix, float hiy, float hiz,
                                           vec3 o, vec3 d, float& t_entry) {
@@ -299,6 +304,11 @@ inline size_t dynamic_lds_bytes(const SceneGpu& sc) {
     if (fits_lds(sc)) b += (size_t)sc.n_records * (16 * LDS_ITEM_F4) + (sc.leaf_inline ? 0 : (size_t)sc.n_refs * 4);
     return b;
 }
+#ifdef PT_TIMELINE
+enum { PT_STAT_WORDS = 16 };  // + the time each wave ran out of rays
+#else
+enum { PT_STAT_WORDS = 8 };
+#endif
 // LDS a workgroup needs for the walk: the staged nodes (and records), four counters, the stacks.
 template <bool KD>
 struct TraceLds {
@@ -306,7 +316,38 @@ struct TraceLds {
     unsigned int* stat;     // 6: hits, slab tests, triangle tests, next ray of the region, wave node steps, wave leaf rounds
     int* stack;             // LdsStack<KD>::ROWS * 256
     float* stack_t;         // the same number of entry distances (kd-tree only)
+    int* count;             // POOL_REGIONS words about the regions the workgroup draws from (pooled source only)
 };
+
+// Pooled ray source.  The regions of a launch are cut into POOL_GROUPS runs of consecutive regions; the workgroups
+// that serve one run (workgroup b serves run b % POOL_GROUPS) share ONE cursor in global memory over the run's rays,
+// handed out in chunks of POOL_CHUNK consecutive queue entries, one chunk per wave at a time.  Which wave traces a
+// ray does not change its hit record, so the rays need not stay with the workgroup whose region holds them.  Why
+// share: a SIMD issues from its oldest waves first, so workgroups with equal shares of the rays finish one after the
+// other (measured on a 5.8 M-ray launch: between 195 and 345 us, the last-placed ones at 447 us) and the chip runs
+// half empty for the second half of the launch; drawing from a pool every wave works until the run is empty (395 us).
+// That pays when one launch has the chip to itself.  With a second batch in flight its kernels fill what the early
+// finishers leave, and private regions are the faster form (the host chooses, see launch_trace's mode).
+// The cursor must be zero when the launch starts.
+enum { POOL_GROUPS = 32, POOL_REGIONS = 64, POOL_CHUNK = 64 };
+struct RayPool {
+    int* cursor;         // next chunk of the run
+    const int* counts;   // rays in each region of the launch (device memory), or nullptr: one flat array of n_fixed rays
+    int n_fixed;
+    int cap_block;       // queue entries per region
+    int first;           // first region of the run
+    int regions;         // regions in the run (<= POOL_REGIONS)
+};
+
+// Inclusive prefix sum over the wave.
+__device__ __forceinline__ int wave_inclusive_sum(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(v, off);
+        v += lane >= off ? up : 0;
+    }
+    return v;
+}
 
 // Copies the top of the tree (and, with ALL_LDS, the leaf records) into LDS; every thread of the
 // workgroup calls it, a barrier must follow before the first walk.
@@ -324,13 +365,15 @@ __device__ __forceinline__ void stage_tree(const SceneGpu& sc, float4* lds_nodes
     }
 }
 
-// Closest hits for the n rays at [region, region + n) of the queue; called by all 256 threads of
-// the workgroup with the tree already staged.  Ends with the workgroup's hit records written and
-// a barrier passed.
-template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS>
+// Closest hits for the n rays at [region, region + n) of the queue (POOL = false) or for the rays
+// the workgroup's waves draw from a pool shared with other workgroups (POOL = true: n and region are
+// unused); called by all 256 threads of the workgroup with the tree already staged.  Ends with the
+// workgroup's hit records written and a barrier passed.
+template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS, bool POOL>
 __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* __restrict__ ray_o,
                                              const float4* __restrict__ ray_d, float4* __restrict__ hit, int n, size_t region,
-                                             unsigned long long* __restrict__ block_stats, int leave_k_and_refill, const TraceLds<KD>& lds) {
+                                             unsigned long long* __restrict__ block_stats, int leave_k_and_refill, const TraceLds<KD>& lds,
+                                             const RayPool& pool) {
     constexpr int LDS_STACK = LdsStack<KD>::ENTRIES;
     float4* const lds_nodes = lds.nodes;
     unsigned int* const s_stat = lds.stat;
@@ -341,6 +384,20 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     float4* const lds_records = lds_nodes + LDS_ITEM_F4 * staged;
     const int* const lds_refs = reinterpret_cast<const int*>(lds_records + LDS_ITEM_F4 * sc.n_records);
     if (threadIdx.x < 6) s_stat[threadIdx.x] = 0;
+    int* const s_count = lds.count;
+    if (POOL) {
+        if (threadIdx.x < POOL_REGIONS) {  // the first wave: chunks up to and including each region of the run
+            int cnt = 0;
+            if ((int)threadIdx.x < pool.regions) {
+                const int r = pool.first + (int)threadIdx.x;
+                if (pool.counts) cnt = pool.counts[r];
+                else { const long long rest = (long long)pool.n_fixed - (long long)r * pool.cap_block; cnt = rest > INT_MAX ? INT_MAX : (int)rest; }
+                cnt = cnt < 0 ? 0 : (cnt > pool.cap_block ? pool.cap_block : cnt);
+            }
+            const int incl = wave_inclusive_sum((cnt + POOL_CHUNK - 1) / POOL_CHUNK, (int)threadIdx.x);
+            s_count[threadIdx.x] = incl * POOL_CHUNK + ((cnt - 1) & (POOL_CHUNK - 1));  // and what its last chunk holds, less one
+        }
+    }
     __syncthreads();
 
     const vec3 rlo = v3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]);
@@ -361,9 +418,30 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     size_t slot = 0;
     float miss_scale = 1.0f;  // the ray's factor on the environment radiance (ray_o.w), handed on in a miss record
     bool fast_ok = false;
+    bool unwritten = false;  // the lane's last ray is finished and its record not yet stored (see write_finished)
     bool drained = false;  // wave-uniform: the region has no unassigned ray left
     const int refill_min = DYNAMIC ? ((leave_k_and_refill >> 8) ? (leave_k_and_refill >> 8) : 16) : 64;
     const int leave_k = leave_k_and_refill & 0xff;
+
+    // pooled source: the wave's current chunk (wave-uniform) and the number of chunks in the run
+    size_t chunk_pos = 0;
+    int chunk_left = 0, n_chunks = 0;
+    if (POOL) n_chunks = s_count[POOL_REGIONS - 1] / POOL_CHUNK;
+    // Takes the wave's next chunk (and asks for the number of the one after): chunks are numbered region by region.
+    auto next_chunk_of_pool = [&]() {
+        int c0 = 0;
+        if (lane == 0) c0 = atomicAdd(pool.cursor, 1);
+        const int c = __builtin_amdgcn_readfirstlane(c0);
+        if (c >= n_chunks) { drained = true; return; }
+        const int packed = s_count[lane];
+        const int j = __popcll(lane_mask(packed / POOL_CHUNK <= c));  // regions that end before chunk c
+        const int before = j > 0 ? __builtin_amdgcn_readlane(packed, j - 1) / POOL_CHUNK : 0;
+        const int here = __builtin_amdgcn_readlane(packed, j);
+        const int piece = c - before;
+        const bool last = piece == here / POOL_CHUNK - before - 1;
+        chunk_pos = (size_t)(pool.first + j) * (size_t)pool.cap_block + (size_t)(piece * POOL_CHUNK);
+        chunk_left = last ? (here & (POOL_CHUNK - 1)) + 1 : POOL_CHUNK;
+    };
 
     // For the lanes that `want` it: takes the next deferred child, or, when none is left, finishes
     // the ray and writes its record.  Called by all lanes of a region of code, with few branches:
@@ -380,6 +458,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 ref = deep[top - LDS_STACK];
                 if (KD) t_ref = deep_t[top - LDS_STACK];
             }
+            wait_for_vector_memory();  // keeps the wait for these rare loads out of the common path
         }
         bool popped = want && top >= 0;
         sp = popped ? top : sp;
@@ -390,7 +469,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     if (sp > 0) {
                         sp--;
                         if (sp < LDS_STACK) { ref = s_stack[sp * 256 + tid]; t_ref = s_stack_t[sp * 256 + tid]; }
-                        else { ref = deep[sp - LDS_STACK]; t_ref = deep_t[sp - LDS_STACK]; }
+                        else { ref = deep[sp - LDS_STACK]; t_ref = deep_t[sp - LDS_STACK]; wait_for_vector_memory(); }
                         again = !(t_ref < best.t);
                     } else {
                         popped = false;
@@ -400,13 +479,20 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             }
         }
         const bool finished = want && !popped;
-        if (finished) {
-            if (best.tri >= 0) n_hit++;
+        n_hit += finished && best.tri >= 0 ? 1u : 0u;
+        unwritten = unwritten || finished;
+        cur = popped ? ref : (finished ? (int)NO_RAY : cur);
+    };
+    // Stores the records of the lanes whose ray is finished.  A finished lane stays idle until the next refill, so
+    // its result can wait in its registers until then: the two walking loops then hold no store to global memory,
+    // and no wait for one either (a wait for outstanding vector-memory operations on gfx950 counts stores as well).
+    auto write_finished = [&]() {
+        if (unwritten) {
             // a miss carries the ray's miss scale where a hit has beta, so the shading stage reads one
             // record per path instead of the ray's origin as well
             hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.tri >= 0 ? best.beta : miss_scale, best.gamma);
         }
-        cur = popped ? ref : (finished ? (int)NO_RAY : cur);
+        unwritten = false;
     };
 
     while (true) {
@@ -415,34 +501,59 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         const int n_idle = __popcll(idle);
         if (n_idle == 64 && drained) break;
         if (!drained && n_idle >= refill_min) {
-            int base = 0;
-            if (lane == 0) base = (int)atomicAdd(&s_stat[3], (unsigned int)n_idle);
-            base = __shfl(base, 0);
-            drained = base + n_idle >= n;
-            const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
-            if (cur == NO_RAY && j < n) {
-                slot = region + j;
-                // camera rays share one origin record (the eye, miss scale 1) and are stored as directions only
-                const float4 ro = ray_o[sc.shared_origin ? 0 : slot], rd = ray_d[slot];
-                o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
-                miss_scale = ro.w;
-                best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
-                sp = 0;
-                if (SLAB == SLAB_RECIP) {
-                    fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
-                    if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
-                }
-                float t_root;
-                if (COUNT) n_box++;
-                const bool in_root = (SLAB == SLAB_RECIP && fast_ok) ? slab_test_recip(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, inv, t_root)
-                                                                     : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
-                if (in_root) {  // src/cs488.h:1438, 1405
-                    cur = sc.root_ref;
-                    leaf_k = 0;
+            write_finished();
+            unsigned long long want = idle;  // lanes still without a ray
+            do {
+                bool mine;
+                size_t cand;
+                if (POOL) {
+                    if (chunk_left == 0) {
+                        next_chunk_of_pool();
+                        if (drained) break;
+                    }
+                    const int asked = __popcll(want);
+                    const int rank = __popcll(want & ((1ull << lane) - 1ull));
+                    mine = ((want >> lane) & 1ull) != 0ull && rank < chunk_left;
+                    cand = chunk_pos + rank;
+                    const int take = asked < chunk_left ? asked : chunk_left;
+                    chunk_pos += take;
+                    chunk_left -= take;
+                    want = lane_mask(((want >> lane) & 1ull) != 0ull && !mine);
                 } else {
-                    hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, ro.w, 0.0f);
+                    int base = 0;
+                    if (lane == 0) base = (int)atomicAdd(&s_stat[3], (unsigned int)n_idle);
+                    base = __shfl(base, 0);
+                    drained = base + n_idle >= n;
+                    const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
+                    mine = cur == NO_RAY && j < n;
+                    cand = region + j;
+                    want = 0ull;
                 }
-            }
+                if (mine) {
+                    slot = cand;
+                    // camera rays share one origin record (the eye, miss scale 1) and are stored as directions only
+                    const float4 ro = ray_o[sc.shared_origin ? 0 : slot], rd = ray_d[slot];
+                    wait_for_vector_memory();  // here, so that no path into the walking loops carries a pending load
+                    o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
+                    miss_scale = ro.w;
+                    best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+                    sp = 0;
+                    if (SLAB == SLAB_RECIP) {
+                        fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
+                        if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
+                    }
+                    float t_root;
+                    if (COUNT) n_box++;
+                    const bool in_root = (SLAB == SLAB_RECIP && fast_ok) ? slab_test_recip(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, inv, t_root)
+                                                                         : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
+                    if (in_root) {  // src/cs488.h:1438, 1405
+                        cur = sc.root_ref;
+                        leaf_k = 0;
+                    } else {
+                        hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, ro.w, 0.0f);
+                    }
+                }
+            } while (want != 0ull);
         }
 
         // ---- node phase: lanes on interior nodes walk until too few of them are left ----
@@ -524,6 +635,10 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         }
     }
 
+    write_finished();
+#ifdef PT_TIMELINE
+    if (lane == 0) s_stat[8 + (tid >> 6)] = (unsigned int)wall_clock64();
+#endif
     // statistics: wave sums -> LDS -> this workgroup's own slots (no global atomics)
     unsigned int tot_hit = n_hit, tot_box = n_box, tot_tri = n_tri, tot_steps = n_wave_steps, tot_rounds = n_wave_rounds;
     for (int off = 32; off > 0; off >>= 1) {

@@ -11,6 +11,11 @@
 // and only that pointer is handed to kernels.
 static __device__ __align__(256) float4 scratch[3 * pt::TRACE_STATIC_MAX_RAYS];
 
+#ifdef PT_TIMELINE
+__device__ unsigned long long g_timeline[4096 * 8];
+extern "C" int pt_debug_timeline(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(g_timeline)); }
+#endif
+
 namespace pt {
 
 namespace {
@@ -21,31 +26,57 @@ enum { SCRATCH_DEVICES = 64 };
 float4* g_scratch_ptr[SCRATCH_DEVICES] = {};  // per device: each GPU holds its own copy at its own address
 std::mutex g_scratch_mutex;
 
-// One 256-lane workgroup per queue region; the region's length is read from device memory
-// (written by the previous stage), so the host never waits for a count.
-template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS>
+// 256-lane workgroups that draw the launch's rays from POOL_GROUPS shared pools (RayPool in trace_device.h): the
+// launch has `n_regions` queue regions of `cap_block` entries, whose ray counts are read from device memory
+// (written by the previous stage, so the host never waits for a count) or follow from n_fixed.
+template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS, bool POOL>
 __global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
                                                     const float4* __restrict__ ray_d, float4* __restrict__ hit,
-                                                    const int* __restrict__ n_ptr, int n_fixed, int cap_block,
-                                                    unsigned long long* __restrict__ block_stats, int leave_k) {
+                                                    const int* __restrict__ n_ptr, int n_fixed, int cap_block, int n_regions,
+                                                    int* __restrict__ cursors, unsigned long long* __restrict__ block_stats,
+                                                    int leave_k) {
     extern __shared__ float4 lds_nodes[];
-    __shared__ __attribute__((aligned(16))) unsigned int s_stat[8];
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[PT_STAT_WORDS];
     __shared__ __attribute__((aligned(16))) int s_stack[LdsStack<KD>::ROWS * 256];
     __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? LdsStack<KD>::ROWS * 256 : 4];
+    __shared__ int s_count[POOL ? POOL_REGIONS : 1];
     const int blk = blockIdx.x;
-    int n;
-    if (n_ptr) {
-        n = n_ptr[blk];
-        n = n < cap_block ? n : cap_block;
-    } else {
-        const long long rest = (long long)n_fixed - (long long)blk * cap_block;
-        n = rest <= 0 ? 0 : (rest < cap_block ? (int)rest : cap_block);
+#ifdef PT_TIMELINE
+    const unsigned long long tl0 = wall_clock64();
+#endif
+    RayPool pool;
+    const int group = blk % POOL_GROUPS;
+    const int per_group = (n_regions + POOL_GROUPS - 1) / POOL_GROUPS;
+    pool.cursor = cursors + group * TRACE_POOL_STRIDE;
+    pool.counts = n_ptr;
+    pool.n_fixed = n_fixed;
+    pool.cap_block = cap_block;
+    pool.first = group * per_group;
+    pool.regions = n_regions - pool.first < per_group ? n_regions - pool.first : per_group;
+    int n = 0;  // POOL = false: the workgroup traces the rays of region blk itself
+    if (!POOL) {
+        if (n_ptr) {
+            n = n_ptr[blk];
+            n = n < cap_block ? n : cap_block;
+        } else {
+            const long long rest = (long long)n_fixed - (long long)blk * cap_block;
+            n = rest <= 0 ? 0 : (rest < cap_block ? (int)rest : cap_block);
+        }
     }
-    if (n <= 0) return;
+    if (POOL ? pool.regions <= 0 : n <= 0) return;
     stage_tree<ALL_LDS>(sc, lds_nodes);
     TraceLds<KD> lds;
-    lds.nodes = lds_nodes; lds.stat = s_stat; lds.stack = s_stack; lds.stack_t = s_stack_t;
-    trace_region<KD, COUNT, SLAB, DYNAMIC, ALL_LDS>(sc, ray_o, ray_d, hit, n, (size_t)blk * cap_block, block_stats, leave_k, lds);
+    lds.nodes = lds_nodes; lds.stat = s_stat; lds.stack = s_stack; lds.stack_t = s_stack_t; lds.count = s_count;
+    trace_region<KD, COUNT, SLAB, DYNAMIC, ALL_LDS, POOL>(sc, ray_o, ray_d, hit, n, (size_t)blk * cap_block, block_stats, leave_k, lds, pool);
+#ifdef PT_TIMELINE
+    if (threadIdx.x == 0 && blk < 4096) {
+        unsigned long long* tl = g_timeline + 8 * (size_t)blk;
+        tl[0] = tl0; tl[1] = wall_clock64();
+        for (int k = 0; k < 4; k++) tl[2 + k] = s_stat[8 + k];
+        tl[6] = 1;
+        tl[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
 }
 
 __global__ void pack_rays_kernel(const float* __restrict__ rays6, int n, float4* ray_o, float4* ray_d) {
@@ -68,24 +99,25 @@ __global__ void unpack_hits_kernel(const float4* __restrict__ hit, int n, int* t
     }
 }
 
-template <bool KD, bool COUNT, int SLAB, bool DYNAMIC>
+template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool POOL>
 void launch_variant(const LaunchCfg& cfg, const SceneGpu& scene, const float4* ray_o, const float4* ray_d, float4* hit,
-                    const int* n_rays, int n_fixed, int grid_blocks, int cap_block, unsigned long long* block_stats, int leave_k) {
+                    const int* n_rays, int n_fixed, int grid_blocks, int cap_block, int* cursors, unsigned long long* block_stats,
+                    int leave_k) {
     const size_t lds = dynamic_lds_bytes(scene);
     if (fits_lds(scene))
-        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, true>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
-                           ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
+        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, true, POOL>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
+                           ray_o, ray_d, hit, n_rays, n_fixed, cap_block, grid_blocks, cursors, block_stats, leave_k);
     else
-        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, false>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
-                           ray_o, ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
+        hipLaunchKernelGGL((trace_kernel<KD, COUNT, SLAB, DYNAMIC, false, POOL>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene,
+                           ray_o, ray_d, hit, n_rays, n_fixed, cap_block, grid_blocks, cursors, block_stats, leave_k);
 }
 
 template <bool KD, bool COUNT>
 void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const float4* ray_o, const float4* ray_d,
-                    float4* hit, const int* n_rays, int n_fixed, int grid_blocks, int cap_block,
+                    float4* hit, const int* n_rays, int n_fixed, int grid_blocks, int cap_block, int* cursors,
                     unsigned long long* block_stats) {
     // mode: bit 0 = reciprocal-form slab test, bit 2 = refill only when the whole wave is idle
-    // (measurement), bits 4..7 = leave_k of the node phase, bits 8..14 = refill threshold (0 = chosen per scene)
+    // (measurement), bit 3 = every workgroup traces its own region instead of drawing from the shared pools, bits 4..7 = leave_k of the node phase, bits 8..14 = refill threshold (0 = chosen per scene)
     const bool recip = (mode & 1) != 0;
     const bool dynamic = (mode & 4) == 0;
     // the refill threshold rides above leave_k; unset, a scene walked entirely in LDS waits for half a wave
@@ -96,13 +128,16 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
     const int k_bits = (mode >> 4) & 15;
     const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 0 : k_bits);
     const int leave_k = k | (refill << 8);
-#define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats, leave_k
-    if (dynamic) {
-        if (recip) launch_variant<KD, COUNT, SLAB_RECIP, true>(PT_ARGS);
-        else launch_variant<KD, COUNT, SLAB_DIVIDE, true>(PT_ARGS);
+#define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats, leave_k
+    if ((mode & 8) != 0) {  // every workgroup traces its own region (always with the dynamic refill)
+        if (recip) launch_variant<KD, COUNT, SLAB_RECIP, true, false>(PT_ARGS);
+        else launch_variant<KD, COUNT, SLAB_DIVIDE, true, false>(PT_ARGS);
+    } else if (dynamic) {
+        if (recip) launch_variant<KD, COUNT, SLAB_RECIP, true, true>(PT_ARGS);
+        else launch_variant<KD, COUNT, SLAB_DIVIDE, true, true>(PT_ARGS);
     } else {
-        if (recip) launch_variant<KD, COUNT, SLAB_RECIP, false>(PT_ARGS);
-        else launch_variant<KD, COUNT, SLAB_DIVIDE, false>(PT_ARGS);
+        if (recip) launch_variant<KD, COUNT, SLAB_RECIP, false, true>(PT_ARGS);
+        else launch_variant<KD, COUNT, SLAB_DIVIDE, false, true>(PT_ARGS);
     }
 #undef PT_ARGS
 }
@@ -111,13 +146,15 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
 
 hipError_t launch_trace(const LaunchCfg& cfg, const SceneGpu& scene, int kd, int count_tests, int mode,
                         const float4* ray_o, const float4* ray_d, float4* hit, const int* n_rays, int n_fixed,
-                        int grid_blocks, int cap_block, unsigned long long* block_stats) {
+                        int grid_blocks, int cap_block, int* cursors, unsigned long long* block_stats) {
+    static_assert((int)POOL_GROUPS == (int)TRACE_POOL_CURSORS, "one cursor per pool");
+    if (grid_blocks > POOL_GROUPS * POOL_REGIONS || !cursors) return hipErrorInvalidValue;
     if (kd) {
-        if (count_tests) launch_by_mode<true, true>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats);
-        else launch_by_mode<true, false>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats);
+        if (count_tests) launch_by_mode<true, true>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats);
+        else launch_by_mode<true, false>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats);
     } else {
-        if (count_tests) launch_by_mode<false, true>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats);
-        else launch_by_mode<false, false>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, block_stats);
+        if (count_tests) launch_by_mode<false, true>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats);
+        else launch_by_mode<false, false>(mode, cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats);
     }
     return hipGetLastError();
 }
@@ -128,8 +165,8 @@ int resident_of(const SceneGpu& scene) {
     int n = 0;
     const size_t lds = dynamic_lds_bytes(scene);
     const hipError_t e = fits_lds(scene)
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<KD, false, SLAB, true, true>, 256, lds)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<KD, false, SLAB, true, false>, 256, lds);
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<KD, false, SLAB, true, true, true>, 256, lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_kernel<KD, false, SLAB, true, false, true>, 256, lds);
     return e == hipSuccess ? n : 0;
 }
 }  // namespace

@@ -25,7 +25,7 @@ def test_every_traversal_setting_gives_the_oracle_hits(gpu_device, obj, accel):
     rays = np.concatenate([rays, extra])
     ref = o.trace(rays)
     s = load_gpu_scene(obj, accel)
-    for mode in (0x00, 0x01, 0x04, 0x05, 0x21, 0x41, 0xF1, 0x2041, 0x0841, 0x4040):
+    for mode in (0x00, 0x01, 0x04, 0x05, 0x08, 0x09, 0x21, 0x41, 0x49, 0xF1, 0x2041, 0x0841, 0x4040):
         s.set_option(pta.OPT_TRAVERSAL, mode)
         got = s.intersect(rays)
         assert np.array_equal(got["tri"], ref["tri"]), hex(mode)
@@ -34,15 +34,36 @@ def test_every_traversal_setting_gives_the_oracle_hits(gpu_device, obj, accel):
     assert s.get_option(pta.OPT_TRAVERSAL) == 0x4040
 
 
+@pytest.mark.parametrize("accel", [pta.BVH, pta.KD])
+def test_pooled_and_private_ray_sources_on_ragged_batches(gpu_device, accel):
+    """pt_trace_batch lets the workgroups draw chunks of 64 rays from shared pools; with bit 3 of the traversal
+    setting every workgroup keeps to its own region.  Batch sizes around the chunk, the wave, the workgroup and the
+    region count (one region per 256 rays up to the resident grid, then longer regions with a ragged last one)."""
+    o = load_oracle_scene("teapot.obj", accel, textures=False)
+    rays = ray_batch(o.get_tris()[0], n_random=600000, n_vertex=600, seed=17)
+    ref = o.trace(rays)
+    s = load_gpu_scene("teapot.obj", accel)
+    for mode in (0x01, 0x09):
+        s.set_option(pta.OPT_TRAVERSAL, mode)
+        for n in (1, 63, 64, 65, 255, 257, 4097, 70001, 524288 + 77, len(rays)):
+            got = s.intersect(rays[:n])
+            assert np.array_equal(got["tri"], ref["tri"][:n]), (hex(mode), n)
+            assert np.array_equal(got["t"].view(np.uint32), ref["t"][:n].view(np.uint32)), (hex(mode), n)
+            assert np.array_equal(got["bary"].view(np.uint32), ref["bary"][:n].view(np.uint32)), (hex(mode), n)
+    s.close()
+
+
 def test_traversal_settings_give_the_same_image(gpu_device):
     imgs = []
-    for mode in (0x00, 0x41, 0x2041):
+    for mode, streams in ((0x00, 2), (0x41, 2), (0x2041, 2), (0x01, 1), (0x09, 1)):  # one stream: pooled unless bit 3
         s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        s.set_option(pta.OPT_STREAMS, streams)
         s.set_option(pta.OPT_TRAVERSAL, mode)
         s.set_resolution(96, 72)
         s.pathtrace(8)
         imgs.append(s.accumulation_buffer())
-    assert np.array_equal(imgs[0], imgs[1])  # same hits, same random numbers, no forks in this scene
+    for im in imgs[1:]:
+        assert np.array_equal(imgs[0], im)  # same hits, same random numbers, no forks in this scene
 
 
 def test_reciprocal_division_is_exact_on_a_slice(gpu_device):

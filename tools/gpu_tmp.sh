@@ -1,1 +1,7 @@
-bash tools/gpu_r2_kd.sh q1 kd
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 1000 python3 -u -m pytest tests -m gpu -x -q --timeout 600 --timeout-method thread > gpurun_out/gpu_tests.txt 2>&1
+rc=$?
+tail -5 gpurun_out/gpu_tests.txt
+exit $rc
