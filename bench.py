@@ -310,8 +310,12 @@ def sponza_record(pta, args, device, stream_handle):
         n_tri = c[pta.CNT_TRI_TESTS] / max(c[pta.CNT_RAYS], 1)
         s.set_option(pta.OPT_COUNT_TESTS, 0)
         # trace_kernel alone: one frame in flight, events around its launches only
+        # (the same kernel as with two frames in flight: traversal bit 3 keeps the workgroups on their own regions,
+        # where a frame rendered alone would otherwise draw from the shared pools)
         lanes = s.get_option(pta.OPT_STREAMS)
+        form = s.get_option(pta.OPT_TRAVERSAL)
         s.set_option(pta.OPT_STREAMS, 1)
+        s.set_option(pta.OPT_TRAVERSAL, form | 8)
         s.pathtrace(sub.spp)
         s.synchronize()
         s.reset_counters()
@@ -325,6 +329,7 @@ def sponza_record(pta, args, device, stream_handle):
         alone_s = ms[pta.TIMER_TRACE] * 1e-3
         s.set_option(pta.OPT_PROFILE, 0)
         s.set_option(pta.OPT_STREAMS, lanes)
+        s.set_option(pta.OPT_TRAVERSAL, form)
         # throughput as the product runs it
         for _ in range(2):
             s.pathtrace(sub.spp)
@@ -484,8 +489,11 @@ def main():
     fence()
     # per-stage milliseconds from a few untimed frames with events around every kernel, one frame in
     # flight at a time (with more, a kernel's span includes the time it shares the chip) ...
+    # (traversal bit 3: the kernel form of the timed region, not the pooled one a lone frame would get)
     streams = scene.get_option(pta.OPT_STREAMS)
+    form = scene.get_option(pta.OPT_TRAVERSAL)
     scene.set_option(pta.OPT_STREAMS, 1)
+    scene.set_option(pta.OPT_TRAVERSAL, form | 8)
     scene.reset_counters()
     scene.set_option(pta.OPT_PROFILE, 1)
     stage_frames = min(args.steps, 5)
@@ -500,6 +508,7 @@ def main():
     stage_ms = [m / stage_frames for m in stage_ms]
     scene.set_option(pta.OPT_PROFILE, 0)
     scene.set_option(pta.OPT_STREAMS, streams)
+    scene.set_option(pta.OPT_TRAVERSAL, form)
     # ... and the timed region with events around the launches of the dominant kernel only
     scene.reset_counters()
     scene.set_option(pta.OPT_PROFILE, 2)
@@ -603,6 +612,7 @@ def main():
                     args.obj or WORKLOADS[args.workload][0] or "sponza stand-in (tools/make_sponza.py)", args.width, args.height,
                     frame_spp if args.strong else args.spp, "" if args.strong else "/GPU", args.accel.upper()),
                 "frames_in_flight": streams, "lane_streams_replaced": int(c[pta.CNT_STREAM_SWAPS]),
+                "lds_nodes": int(scene.get_option(pta.OPT_LDS_NODES)),
                 "parallelism": ("sample-split x%d + %s reduce of the accumulation buffer" % (
                     world, "RCCL" if args.backend == "nccl" else "gloo (host-staged rehearsal)")) if collective else "single GPU",
             },

@@ -282,8 +282,10 @@ template <bool KD> struct LdsStack { enum { ROWS = KD ? LDS_STACK_ROWS_KD : LDS_
 // Triangles a lane tests per visit of the leaf phase.
 enum { LEAF_BURST = 4 };
 
-// A lane's `cur`: >= 0 interior node, < 0 leaf (~offset of its first record), NO_RAY = no ray.
-enum : int { NO_RAY = INT_MIN };
+// A lane's `cur`: >= 0 interior node, < 0 leaf (~offset of its first record), NO_RAY = no ray, RAY_DONE = no ray
+// and the record of the last one still to be stored (EMPTY_LEAF, INT_MIN + 1, lies between the two and is never
+// a lane's position).  Leaf offsets stay far below 2^31 - 3, so every leaf reference is above RAY_DONE.
+enum : int { NO_RAY = INT_MIN, RAY_DONE = INT_MIN + 2 };
 
 // Nodes and records staged in LDS are 64 bytes each but stored 80 bytes apart (five float4): with a stride of 64
 // bytes every node's quarter p would start at one of only four bank positions, so lanes of one ds_read_b128 that read
@@ -418,7 +420,6 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     size_t slot = 0;
     float miss_scale = 1.0f;  // the ray's factor on the environment radiance (ray_o.w), handed on in a miss record
     bool fast_ok = false;
-    bool unwritten = false;  // the lane's last ray is finished and its record not yet stored (see write_finished)
     bool drained = false;  // wave-uniform: the region has no unassigned ray left
     const int refill_min = DYNAMIC ? ((leave_k_and_refill >> 8) ? (leave_k_and_refill >> 8) : 16) : 64;
     const int leave_k = leave_k_and_refill & 0xff;
@@ -479,81 +480,86 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             }
         }
         const bool finished = want && !popped;
-        n_hit += finished && best.tri >= 0 ? 1u : 0u;
-        unwritten = unwritten || finished;
-        cur = popped ? ref : (finished ? (int)NO_RAY : cur);
+        cur = popped ? ref : (finished ? (int)RAY_DONE : cur);
     };
     // Stores the records of the lanes whose ray is finished.  A finished lane stays idle until the next refill, so
     // its result can wait in its registers until then: the two walking loops then hold no store to global memory,
     // and no wait for one either (a wait for outstanding vector-memory operations on gfx950 counts stores as well).
     auto write_finished = [&]() {
-        if (unwritten) {
+        if (cur == RAY_DONE) {
+            if (best.tri >= 0) n_hit++;
             // a miss carries the ray's miss scale where a hit has beta, so the shading stage reads one
             // record per path instead of the ray's origin as well
             hit[slot] = make_float4(__int_as_float(best.tri), best.t, best.tri >= 0 ? best.beta : miss_scale, best.gamma);
+            cur = NO_RAY;
         }
-        unwritten = false;
     };
 
     while (true) {
         // ---- idle lanes take the next rays of the region, once enough of them are idle ----
-        const unsigned long long idle = lane_mask(cur == NO_RAY);
+        const unsigned long long idle = lane_mask(cur <= RAY_DONE);
         const int n_idle = __popcll(idle);
         if (n_idle == 64 && drained) break;
         if (!drained && n_idle >= refill_min) {
-            write_finished();
-            unsigned long long want = idle;  // lanes still without a ray
-            do {
-                bool mine;
-                size_t cand;
-                if (POOL) {
+            bool mine = false;   // the lane takes a new ray, the one at queue entry `cand`
+            size_t cand = 0;
+            if (POOL) {
+                unsigned long long want = idle;  // lanes still without a ray
+                while (want != 0ull) {
                     if (chunk_left == 0) {
                         next_chunk_of_pool();
                         if (drained) break;
                     }
                     const int asked = __popcll(want);
                     const int rank = __popcll(want & ((1ull << lane) - 1ull));
-                    mine = ((want >> lane) & 1ull) != 0ull && rank < chunk_left;
-                    cand = chunk_pos + rank;
+                    const bool got = ((want >> lane) & 1ull) != 0ull && rank < chunk_left;
+                    cand = got ? chunk_pos + rank : cand;
+                    mine = mine || got;
                     const int take = asked < chunk_left ? asked : chunk_left;
                     chunk_pos += take;
                     chunk_left -= take;
-                    want = lane_mask(((want >> lane) & 1ull) != 0ull && !mine);
+                    want = lane_mask(((want >> lane) & 1ull) != 0ull && !got);
+                }
+            } else {
+                int base = 0;
+                if (lane == 0) base = (int)atomicAdd(&s_stat[3], (unsigned int)n_idle);
+                base = __shfl(base, 0);
+                drained = base + n_idle >= n;
+                const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
+                mine = cur <= RAY_DONE && j < n;
+                cand = region + j;
+            }
+            // The new rays are loaded and waited for first, the records of the finished ones stored after that
+            // wait: nothing then ever waits for those stores (a wait for vector memory counts loads and stores alike).
+            float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = ro;
+            if (mine) {
+                // camera rays share one origin record (the eye, miss scale 1) and are stored as directions only
+                ro = ray_o[sc.shared_origin ? 0 : cand];
+                rd = ray_d[cand];
+            }
+            wait_for_vector_memory();  // here, so that no path into the walking loops carries a pending load
+            write_finished();
+            if (mine) {
+                slot = cand;
+                o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
+                miss_scale = ro.w;
+                best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+                sp = 0;
+                if (SLAB == SLAB_RECIP) {
+                    fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
+                    if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
+                }
+                float t_root;
+                if (COUNT) n_box++;
+                const bool in_root = (SLAB == SLAB_RECIP && fast_ok) ? slab_test_recip(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, inv, t_root)
+                                                                     : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
+                if (in_root) {  // src/cs488.h:1438, 1405
+                    cur = sc.root_ref;
+                    leaf_k = 0;
                 } else {
-                    int base = 0;
-                    if (lane == 0) base = (int)atomicAdd(&s_stat[3], (unsigned int)n_idle);
-                    base = __shfl(base, 0);
-                    drained = base + n_idle >= n;
-                    const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
-                    mine = cur == NO_RAY && j < n;
-                    cand = region + j;
-                    want = 0ull;
+                    hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, ro.w, 0.0f);
                 }
-                if (mine) {
-                    slot = cand;
-                    // camera rays share one origin record (the eye, miss scale 1) and are stored as directions only
-                    const float4 ro = ray_o[sc.shared_origin ? 0 : slot], rd = ray_d[slot];
-                    wait_for_vector_memory();  // here, so that no path into the walking loops carries a pending load
-                    o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
-                    miss_scale = ro.w;
-                    best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
-                    sp = 0;
-                    if (SLAB == SLAB_RECIP) {
-                        fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
-                        if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
-                    }
-                    float t_root;
-                    if (COUNT) n_box++;
-                    const bool in_root = (SLAB == SLAB_RECIP && fast_ok) ? slab_test_recip(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, inv, t_root)
-                                                                         : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
-                    if (in_root) {  // src/cs488.h:1438, 1405
-                        cur = sc.root_ref;
-                        leaf_k = 0;
-                    } else {
-                        hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, ro.w, 0.0f);
-                    }
-                }
-            } while (want != 0ull);
+            }
         }
 
         // ---- node phase: lanes on interior nodes walk until too few of them are left ----
@@ -561,7 +567,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         while (true) {
             const int walking = __popcll(lane_mask(cur >= 0));
             if (walking == 0) break;
-            if (leave_k > 0 && walking * leave_k < __popcll(lane_mask((unsigned int)cur > (unsigned int)NO_RAY))) break;
+            if (leave_k > 0 && walking * leave_k < __popcll(lane_mask((unsigned int)cur > (unsigned int)RAY_DONE))) break;
             if (COUNT) n_wave_steps += lane == 0 ? 1 : 0;
             if (cur >= 0) {
                 float4 q0, q1, q2, q3;
@@ -599,7 +605,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         // order (src/cs488.h:1677-1681, 1350-1354); a larger leaf is finished in the next round, so
         // one big leaf does not hold the other lanes.  A lane whose leaf ends earlier repeats its
         // last record with the result switched off, so the rounds need no per-lane control flow.
-        if ((unsigned int)cur > (unsigned int)NO_RAY) {
+        if ((unsigned int)cur > (unsigned int)RAY_DONE) {
             const int off = ~cur;
             if (KD && !sc.leaf_inline) {
                 const int n_here = ALL_LDS ? lds_refs[off] : sc.refs[off];
