@@ -495,40 +495,71 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         }
     };
 
+    // Hands the next unassigned queue entries to the lanes of `want`: `mine` says whether the lane got one, `cand`
+    // which.  Sets `drained` when nothing is left for the wave.
+    auto assign = [&](unsigned long long want, bool& mine, size_t& cand) {
+        mine = false;
+        cand = 0;
+        if (POOL) {
+            while (want != 0ull) {
+                if (chunk_left == 0) {
+                    next_chunk_of_pool();
+                    if (drained) break;
+                }
+                const int asked = __popcll(want);
+                const int rank = __popcll(want & ((1ull << lane) - 1ull));
+                const bool got = ((want >> lane) & 1ull) != 0ull && rank < chunk_left;
+                cand = got ? chunk_pos + rank : cand;
+                mine = mine || got;
+                const int take = asked < chunk_left ? asked : chunk_left;
+                chunk_pos += take;
+                chunk_left -= take;
+                want = lane_mask(((want >> lane) & 1ull) != 0ull && !got);
+            }
+        } else {
+            const int asked = __popcll(want);
+            int base = 0;
+            if (lane == 0) base = (int)atomicAdd(&s_stat[3], (unsigned int)asked);
+            base = __shfl(base, 0);
+            drained = base + asked >= n;
+            const int j = base + __popcll(want & ((1ull << lane) - 1ull));
+            mine = ((want >> lane) & 1ull) != 0ull && j < n;
+            cand = region + j;
+        }
+    };
+    // Starts the ray (ro, rd) of queue entry `at` on this lane: reciprocals, root box.
+    auto start_ray = [&](size_t at, const float4& ro, float dx, float dy, float dz) {
+        slot = at;
+        o = v3(ro.x, ro.y, ro.z); d = v3(dx, dy, dz);
+        miss_scale = ro.w;
+        best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
+        sp = 0;
+        if (SLAB == SLAB_RECIP) {
+            fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
+            if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
+        }
+        float t_root;
+        if (COUNT) n_box++;
+        const bool in_root = (SLAB == SLAB_RECIP && fast_ok) ? slab_test_recip(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, inv, t_root)
+                                                             : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
+        if (in_root) {  // src/cs488.h:1438, 1405
+            cur = sc.root_ref;
+            leaf_k = 0;
+        } else {
+            hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, ro.w, 0.0f);
+        }
+    };
+
+
     while (true) {
         // ---- idle lanes take the next rays of the region, once enough of them are idle ----
         const unsigned long long idle = lane_mask(cur <= RAY_DONE);
         const int n_idle = __popcll(idle);
         if (n_idle == 64 && drained) break;
         if (!drained && n_idle >= refill_min) {
-            bool mine = false;   // the lane takes a new ray, the one at queue entry `cand`
-            size_t cand = 0;
-            if (POOL) {
-                unsigned long long want = idle;  // lanes still without a ray
-                while (want != 0ull) {
-                    if (chunk_left == 0) {
-                        next_chunk_of_pool();
-                        if (drained) break;
-                    }
-                    const int asked = __popcll(want);
-                    const int rank = __popcll(want & ((1ull << lane) - 1ull));
-                    const bool got = ((want >> lane) & 1ull) != 0ull && rank < chunk_left;
-                    cand = got ? chunk_pos + rank : cand;
-                    mine = mine || got;
-                    const int take = asked < chunk_left ? asked : chunk_left;
-                    chunk_pos += take;
-                    chunk_left -= take;
-                    want = lane_mask(((want >> lane) & 1ull) != 0ull && !got);
-                }
-            } else {
-                int base = 0;
-                if (lane == 0) base = (int)atomicAdd(&s_stat[3], (unsigned int)n_idle);
-                base = __shfl(base, 0);
-                drained = base + n_idle >= n;
-                const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
-                mine = cur <= RAY_DONE && j < n;
-                cand = region + j;
-            }
+            bool mine;   // the lane takes a new ray, the one at queue entry `cand`
+            size_t cand;
+            assign(idle, mine, cand);
             // The new rays are loaded and waited for first, the records of the finished ones stored after that
             // wait: nothing then ever waits for those stores (a wait for vector memory counts loads and stores alike).
             float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = ro;
@@ -539,27 +570,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             }
             wait_for_vector_memory();  // here, so that no path into the walking loops carries a pending load
             write_finished();
-            if (mine) {
-                slot = cand;
-                o = v3(ro.x, ro.y, ro.z); d = v3(rd.x, rd.y, rd.z);
-                miss_scale = ro.w;
-                best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
-                sp = 0;
-                if (SLAB == SLAB_RECIP) {
-                    fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
-                    if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
-                }
-                float t_root;
-                if (COUNT) n_box++;
-                const bool in_root = (SLAB == SLAB_RECIP && fast_ok) ? slab_test_recip(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, inv, t_root)
-                                                                     : slab_test(rlo.x, rlo.y, rlo.z, rhi.x, rhi.y, rhi.z, o, d, t_root);
-                if (in_root) {  // src/cs488.h:1438, 1405
-                    cur = sc.root_ref;
-                    leaf_k = 0;
-                } else {
-                    hit[slot] = make_float4(__int_as_float(-1), FLT_MAX, ro.w, 0.0f);
-                }
-            }
+            if (mine) start_ray(cand, ro, rd.x, rd.y, rd.z);
         }
 
         // ---- node phase: lanes on interior nodes walk until too few of them are left ----
