@@ -35,6 +35,8 @@
 #include <float.h>
 #include <limits.h>
 
+#include <type_traits>
+
 #include "device_math.h"
 #include "device_types.h"
 #include "pt_math.h"
@@ -575,6 +577,10 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
 
         // ---- node phase: lanes on interior nodes walk until too few of them are left ----
         // (leave when nobody walks, or when the walkers are fewer than 1/k of the lanes waiting at a leaf)
+        // Written once and instantiated twice: which slab form the wave uses can only change at a refill, and a loop
+        // that holds one form has neither the test nor the merges of the two forms' results in every step.
+        auto node_phase = [&](auto fast_form) {
+        constexpr bool FAST = decltype(fast_form)::value;
         while (true) {
             const int walking = __popcll(lane_mask(cur >= 0));
             if (walking == 0) break;
@@ -591,8 +597,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 }
                 if (COUNT) n_box += 2;
                 NodeStep st;
-                // one form for the whole wave: the division form is right for every ray
-                if (SLAB == SLAB_RECIP && lane_mask(!fast_ok) == 0ull) node_step_recip<KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
+                if (FAST) node_step_recip<KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
                 else node_step<false, KD>(q0, q1, q2, q3, o, d, inv, best.t, st);
                 // the deferred child goes to the row above the top whether or not it is pushed (that row
                 // is dead until it is), or to the spare row once the lane's LDS rows are full
@@ -611,6 +616,10 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 leaf_k = 0;
             }
         }
+        };
+        // one form for the whole wave: the division form is right for every ray
+        if (SLAB == SLAB_RECIP && lane_mask(cur > RAY_DONE && !fast_ok) == 0ull) node_phase(std::true_type());
+        else node_phase(std::false_type());
 
         // ---- leaf phase: every lane on a leaf tests up to LEAF_BURST of its triangles, in stored
         // order (src/cs488.h:1677-1681, 1350-1354); a larger leaf is finished in the next round, so

@@ -1,22 +1,19 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 env PT_AMD_LIB=$PWD/ab_libs/libpt_ahead.so python3 -u -m pytest tests/test_gpu_trace_parity.py tests/test_gpu_modes_and_cli.py -x -q --timeout 300 --timeout-method thread -k "not cli" > gpurun_out/tl_parity.txt 2>&1 || { tail -20 gpurun_out/tl_parity.txt; exit 1; }
-tail -1 gpurun_out/tl_parity.txt
+true
+true
 B="python3 bench.py --no-pmc --no-sponza --no-cpu-baseline --no-kd --steps 30 --warmup 5"
 run() { name=$1; lib=$2; shift; shift; PT_AMD_LIB=$PWD/ab_libs/libpt_$lib.so timeout -k 10 300 $B "$@" > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err || return 1; python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/ab_$name.json').read().strip().splitlines()[-1])
 print('%-26s %8.0f Mrays/s %7.3f ms  alone %.3f ms' % ('$name', d['value'], d['ms_per_step'], d['roofline']['alone']['avg_launch_ms']))"; }
-for rep in 1 2; do for r in base refac ahead; do
+for rep in 1 2; do for r in base two; do
 run ${r}_bvh $r || exit 1
 run ${r}_kd $r --accel kd || exit 1
 done; done
-for t in 4 8 16 24 48; do
-run ahead_bvh_r$t ahead --traversal $(( 1 + (t << 8) )) || exit 1
-run ahead_kd_r$t ahead --accel kd --traversal $(( 1 + (t << 8) )) || exit 1
-done
-for r in base ahead; do
+for r in base two; do
+run ${r}_alpha $r --workload cornellbox-alpha || exit 1
 run ${r}_teapot $r --workload teapot || exit 1
 run ${r}_teapot_kd $r --workload teapot --accel kd || exit 1
 run ${r}_sponza $r --workload sponza --steps 6 --warmup 2 || exit 1
