@@ -1,22 +1,26 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-true
-true
 B="python3 bench.py --no-pmc --no-sponza --no-cpu-baseline --no-kd --steps 30 --warmup 5"
-run() { name=$1; lib=$2; shift; shift; PT_AMD_LIB=$PWD/ab_libs/libpt_$lib.so timeout -k 10 300 $B "$@" > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err || return 1; python3 -c "
+run() { name=$1; shift; timeout -k 10 300 $B "$@" > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err || return 1; python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/ab_$name.json').read().strip().splitlines()[-1])
-print('%-26s %8.0f Mrays/s %7.3f ms  alone %.3f ms' % ('$name', d['value'], d['ms_per_step'], d['roofline']['alone']['avg_launch_ms']))"; }
-for rep in 1 2; do for r in base two; do
-run ${r}_bvh $r || exit 1
-run ${r}_kd $r --accel kd || exit 1
-done; done
-for r in base two; do
-run ${r}_alpha $r --workload cornellbox-alpha || exit 1
-run ${r}_teapot $r --workload teapot || exit 1
-run ${r}_teapot_kd $r --workload teapot --accel kd || exit 1
-run ${r}_sponza $r --workload sponza --steps 6 --warmup 2 || exit 1
-run ${r}_sponza_kd $r --workload sponza --accel kd --steps 4 --warmup 1 || exit 1
+print('%-26s %8.0f Mrays/s %7.3f ms  swaps %s' % ('$name', d['value'], d['ms_per_step'], d['config'].get('lane_streams_replaced')))"; }
+for rep in 1 2; do
+run s2_bvh || exit 1
+run s3_bvh --streams 3 || exit 1
+run s4_bvh --streams 4 || exit 1
+run s2_kd --accel kd || exit 1
+run s3_kd --accel kd --streams 3 || exit 1
+run s2_coll --force-collective || exit 1
+run s3_coll --force-collective --streams 3 || exit 1
 done
+run s2_teapot --workload teapot || exit 1
+run s3_teapot --workload teapot --streams 3 || exit 1
+run s2_alpha --workload cornellbox-alpha || exit 1
+run s3_alpha --workload cornellbox-alpha --streams 3 || exit 1
+run s2_glass --workload cornellbox-glass || exit 1
+run s3_glass --workload cornellbox-glass --streams 3 || exit 1
+run s2_sponza --workload sponza --steps 6 --warmup 2 || exit 1
+run s3_sponza --workload sponza --steps 6 --warmup 2 --streams 3 || exit 1
 echo rc=$?
