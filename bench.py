@@ -310,7 +310,7 @@ def sponza_record(pta, args, device, stream_handle):
         n_tri = c[pta.CNT_TRI_TESTS] / max(c[pta.CNT_RAYS], 1)
         s.set_option(pta.OPT_COUNT_TESTS, 0)
         # trace_kernel alone: one frame in flight, events around its launches only
-        # (the same kernel as with two frames in flight: traversal bit 3 keeps the workgroups on their own regions,
+        # (the same kernel as with several frames in flight: traversal bit 3 keeps the workgroups on their own regions,
         # where a frame rendered alone would otherwise draw from the shared pools)
         lanes = s.get_option(pta.OPT_STREAMS)
         form = s.get_option(pta.OPT_TRAVERSAL)

@@ -95,7 +95,10 @@ enum {
     PT_OPT_TREE_IN_LDS = 14,  /* read only: 1 when the built scene's whole tree and its intersection records are staged in LDS by
                                  the trace kernels (small scenes: the walk then has no global-memory path, so instruction
                                  issue and not memory bandwidth bounds it) */
-    PT_OPT_STREAMS = 13       /* batches in flight, 1..4 (default 2).  Consecutive batches (frames, when a frame is one
+    PT_OPT_STREAMS = 13       /* batches in flight, 1..4.  Unless set, pt_build chooses: 3, or 2 for a scene whose tree is walked
+                                 in LDS and has no translucent surface (a third batch gains nothing there); and 2 from the
+                                 moment the context joins a group or is given an external per-frame buffer, which leaves a
+                                 hardware queue to the collective library.  Consecutive batches (frames, when a frame is one
                                  batch) run on internal streams with queues of their own, so the thinly populated late
                                  levels of one overlap the early levels of the next; the kernels that touch the image
                                  (accumulate, resolve, clear) stay on the context's stream in program order, so the image

@@ -140,7 +140,8 @@ struct PtContext {
     float* ext_accum = nullptr;
     PtGroup* group = nullptr;             // set while the context is a member of a multi-GPU group
     Lane lanes[MAX_LANES];
-    int n_lanes = 2;                      // batches in flight (PT_OPT_STREAMS)
+    int n_lanes = 3;                      // batches in flight (PT_OPT_STREAMS)
+    bool lanes_auto = true;               // not set by the caller: chosen per scene in pt_build; two once a collective library shares the GPU's queues
     bool lanes_checked = false;           // the lanes' streams have been probed for running side by side
     int lane_stream_swaps = 0;            // streams replaced by that probe
     DeviceBuffer<unsigned long long> d_totals;
@@ -437,6 +438,17 @@ int flatten_and_upload(PtContext* c) {
         if (!(hm2.opacity >= 1.0f - PT_EPSILON)) s.fixed_radiance = 1;  // the alpha fork of src/cs488.h:2038
     s.shading_kind = (other || (metal && glass)) ? 0 : (glass ? 3 : (metal ? 4 : (plain ? 2 : 1)));
     choose_lds_nodes(c);
+    if (c->lanes_auto && !c->ext_accum && !c->group) {
+        // Batches in flight, unless the caller chose: three -- except for a scene whose tree is walked in LDS and whose
+        // paths do not fork, where the third brings nothing (cornellbox: +0.3 %, its kd-tree -1 %; teapot +14 %,
+        // cornellbox-alpha +5 %, a 210 k-triangle courtyard +4 %) and costs a lane's queues.
+        const int lanes = (s.lds_nodes >= s.n_nodes && !s.fixed_radiance) ? 2 : 3;
+        if (lanes != c->n_lanes) {
+            if (c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+            c->n_lanes = lanes;
+            c->lanes_checked = false;
+        }
+    }
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)
         for (int k = 0; k < 6; k++)
@@ -590,8 +602,10 @@ void shape_batch(PtContext* c, const Lane& ln, bool own_stream, BatchGpu& b) {
     int nb = (b.n_slots + 2047) / 2048;
     if (c->resident_per_cu <= 0) c->resident_per_cu = trace_resident_blocks_per_cu(c->scene, c->accel == PT_ACCEL_KD, c->traversal);
     // with another batch in flight beside this one, five regions per CU leave its kernels room (measured: 5 or 6
-    // instead of 8 gains 3-5 % on the cornellbox and the teapot, nothing elsewhere)
-    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (own_stream && c->resident_per_cu > 5 ? 5 : c->resident_per_cu);
+    // instead of 8 gains 3-5 % on the cornellbox and the teapot, nothing elsewhere); with two others, four do
+    // where the tree is walked in LDS (+0.5-1.5 %; a tree in memory wants its five: -1 % with four)
+    const int beside = !own_stream ? c->resident_per_cu : (c->n_lanes >= 3 && c->scene.lds_nodes >= c->scene.n_nodes ? 4 : 5);
+    const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (beside < c->resident_per_cu ? beside : c->resident_per_cu);
     const int most = c->cus * per_cu;
     nb = nb < 1 ? 1 : (nb > most ? most : nb);
     b.blocks = nb;
@@ -913,7 +927,7 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
         case PT_OPT_STREAMS:
             if (value < 1 || value > MAX_LANES) return fail(c, PT_ERR_INVALID_ARG, "between 1 and 4 batches in flight");
             if (c->device != PT_DEVICE_NONE && c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
-            c->n_lanes = (int)value; c->lanes_checked = false; break;
+            c->n_lanes = (int)value; c->lanes_auto = false; c->lanes_checked = false; break;
         case PT_OPT_TAIL_LEVEL:
             if (value > 64 && value != 255) return fail(c, PT_ERR_INVALID_ARG, "tail level above 64");
             c->tail_level = (int)value; break;
@@ -1196,10 +1210,25 @@ int pt_download(PtContext* c, int which, float* dst) {
 
 void* pt_accum_device_ptr(PtContext* c) { return c ? (void*)c->accum_ptr() : nullptr; }
 
+// A process has four hardware queues per GPU (GPU_MAX_HW_QUEUES): the context's stream and three lanes fill
+// them.  Once the context's frames go into a collective, the collective library's own stream needs one, so a
+// context whose number of lanes the caller has not chosen keeps two from then on.
+static int leave_a_queue_for_the_collective(PtContext* c) {
+    if (!c->lanes_auto || c->n_lanes <= 2) return PT_OK;
+    if (c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+    c->n_lanes = 2;
+    c->lanes_checked = false;
+    return PT_OK;
+}
+
 int pt_use_external_accum(PtContext* c, void* device_ptr) {
     if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    if (device_ptr) {
+        const int rc = leave_a_queue_for_the_collective(c);  // waits once, the first time
+        if (rc != PT_OK) return rc;
+    }
     // no wait: everything that touches the buffers is ordered on the context's stream
     c->ext_accum = (float*)device_ptr;
     return PT_OK;
@@ -1571,6 +1600,7 @@ int pt_group_create(int n, PtContext* const* members, PtGroup** out) {
                 return PT_ERR_HIP;
             }
             c->ext_accum = g->delta[i];  // from here on the member's batches accumulate into its per-frame buffer
+            (void)leave_a_queue_for_the_collective(c);
         }
         *out = g;
         int rc = pt_group_reset(g);

@@ -60,7 +60,7 @@ def test_python_constants_equal_the_header_enums():
     h = ctypes.c_void_p()
     L = pta.lib()
     assert L.pt_create(pta.DEVICE_NONE, ctypes.byref(h)) == pta.PT_OK
-    assert L.pt_get_option(h, pta.OPT_STREAMS, ctypes.byref(v)) == pta.PT_OK and v.value == 2
+    assert L.pt_get_option(h, pta.OPT_STREAMS, ctypes.byref(v)) == pta.PT_OK and v.value == 3
     assert L.pt_set_option(h, pta.OPT_STREAMS, ctypes.c_uint64(5)) == pta.ERR_INVALID_ARG
     L.pt_destroy(h)
 

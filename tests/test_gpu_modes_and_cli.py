@@ -284,6 +284,38 @@ def test_frames_in_flight_do_not_change_the_image(gpu_device, obj, accel):
 
 
 @pytest.mark.gpu
+def test_batches_in_flight_are_chosen_per_scene(gpu_device):
+    """Unless the caller sets PT_OPT_STREAMS, pt_build chooses: two batches in flight for a scene walked in LDS
+    without translucent surfaces, three otherwise; a context whose frames go into a collective (an external
+    per-frame buffer) keeps two; a value the caller set is left alone."""
+    for obj, want in (("cornellbox.obj", 2), ("cornellbox-alpha.obj", 3), ("teapot.obj", 3)):
+        s = load_gpu_scene(obj, pta.BVH)
+        assert s.get_option(pta.OPT_STREAMS) == want, obj
+        s.close()
+    s = pta.Scene(gpu_device)
+    s.set_option(pta.OPT_STREAMS, 4)
+    assert s.load(scene_path("cornellbox.obj"))
+    s.pre_calc(pta.BVH)
+    assert s.get_option(pta.OPT_STREAMS) == 4
+    s.close()
+    from common import DeviceArray
+    s = load_gpu_scene("teapot.obj", pta.BVH, env="probe_64.hdr")
+    s.set_resolution(64, 48)
+    s.pathtrace(2)
+    own = s.accumulation_buffer()
+    buf = DeviceArray(np.zeros(64 * 48 * 3, np.float32))
+    s.use_external_accum(buf.ptr.value)
+    assert s.get_option(pta.OPT_STREAMS) == 2
+    s.reset()
+    s.pathtrace(2)
+    s.synchronize()
+    assert np.array_equal(buf.download().reshape(own.shape), own)
+    s.use_external_accum(0)
+    s.close()
+    buf.free()
+
+
+@pytest.mark.gpu
 def test_cli_scripted_input(gpu_device, tmp_path):
     """Scripted events stand in for the window's callbacks (src/cs488.h:240-349): a translation keeps
     accumulating (the reference restarts only when view direction or right vector change, :2266-2293),
