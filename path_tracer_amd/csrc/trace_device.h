@@ -334,6 +334,8 @@ struct TraceLds {
 // finishers leave, and private regions are the faster form (the host chooses, see launch_trace's mode).
 // The cursor must be zero when the launch starts.
 enum { POOL_GROUPS = 32, POOL_REGIONS = 64, POOL_CHUNK = 64 };
+// most queue entries per region the pooled source serves: 64 regions' chunk counts x 64 must fit an int
+enum { POOL_MAX_REGION = 1 << 24 };
 struct RayPool {
     int* cursor;         // next chunk of the run
     const int* counts;   // rays in each region of the launch (device memory), or nullptr: one flat array of n_fixed rays
@@ -430,7 +432,8 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     size_t chunk_pos = 0;
     int chunk_left = 0, n_chunks = 0;
     if (POOL) n_chunks = s_count[POOL_REGIONS - 1] / POOL_CHUNK;
-    // Takes the wave's next chunk (and asks for the number of the one after): chunks are numbered region by region.
+    // Takes the wave's next chunk: chunks are numbered region by region, s_count[r] = 64 x (chunks up to and including
+    // region r) + (rays in r's last chunk - 1).
     auto next_chunk_of_pool = [&]() {
         int c0 = 0;
         if (lane == 0) c0 = atomicAdd(pool.cursor, 1);
@@ -446,8 +449,8 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         chunk_left = last ? (here & (POOL_CHUNK - 1)) + 1 : POOL_CHUNK;
     };
 
-    // For the lanes that `want` it: takes the next deferred child, or, when none is left, finishes
-    // the ray and writes its record.  Called by all lanes of a region of code, with few branches:
+    // For the lanes that `want` it: takes the next deferred child, or, when none is left, marks the
+    // ray finished (its record is stored at the next refill).  Called by all lanes of a region of code, with few branches:
     // the LDS row is read unconditionally (clamped), deep entries and skipped kd entries are rare
     // and handled behind wave-wide tests.
     auto pop_or_finish = [&](bool want) {

@@ -129,7 +129,7 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
     const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 0 : k_bits);
     const int leave_k = k | (refill << 8);
 #define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats, leave_k
-    if ((mode & 8) != 0) {  // every workgroup traces its own region (always with the dynamic refill)
+    if ((mode & 8) != 0 || cap_block > POOL_MAX_REGION) {  // every workgroup traces its own region (always with the dynamic refill)
         if (recip) launch_variant<KD, COUNT, SLAB_RECIP, true, false>(PT_ARGS);
         else launch_variant<KD, COUNT, SLAB_DIVIDE, true, false>(PT_ARGS);
     } else if (dynamic) {
