@@ -70,6 +70,9 @@ __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float
     return true;
 }
 
+// a.x + a.y + a.z, in that order
+__device__ __forceinline__ float sum3(vec3 a) { return (a.x + a.y) + a.z; }
+
 struct Best {
     float t, beta, gamma;
     int tri;
@@ -128,10 +131,14 @@ __device__ __forceinline__ void triangle_round(const float4& r0, const float4& r
     const vec3 b = v3(r2.x, r2.y, r2.z);
     const vec3 ab = v3(r3.x, r3.y, r3.z);
     const vec3 e = v3(r0.x, r0.y, r0.z) - o;
-    const float D = dot(ab, d);
-    const float Da = dot(cross(e, b), d);
-    const float Db = dot(cross(a, e), d);
-    const float Dc = dot(ab, e);
+    // The reference's dot product starts its sum at 0 (src/linalg.h:401, 501), which changes one thing only: a
+    // sum of three products that are all -0 comes out as +0.  The sums are formed without that addition here; the
+    // sign of a zero determinant is never looked at, a zero numerator always takes the division form below, and
+    // there the three numerators get their + 0 back.
+    const float D = sum3(ab * d);
+    float Da = sum3(cross(e, b) * d);
+    float Db = sum3(cross(a, e) * d);
+    float Dc = sum3(ab * e);
     const bool live = valid && D != 0;
     bool guarded = false;
     if (FAST_DIV) {
@@ -152,6 +159,7 @@ __device__ __forceinline__ void triangle_round(const float4& r0, const float4& r
         const float most = fmaxf(fmaxf(alpha, beta), gamma);
         accept = live && least >= 0.0f && most <= 1.0f && t < best.t;
     } else {
+        Da = 0.0f + Da; Db = 0.0f + Db; Dc = 0.0f + Dc;
         beta = Da / D;
         gamma = Db / D;
         t = Dc / D;
@@ -294,6 +302,11 @@ enum : int { NO_RAY = INT_MIN, RAY_DONE = INT_MIN + 2 };
 // different nodes would collide four to one and worse; 20 dwords apart, sixteen consecutive nodes start at sixteen
 // different multiples of four banks.
 enum { LDS_ITEM_F4 = 5 };
+// Item `i` of an LDS array of such items.  The index is small, so the offset is a 24-bit multiply-add (full
+// rate) where plain pointer arithmetic compiles to a 32-bit multiply (quarter rate on gfx950) in every step.
+__device__ __forceinline__ const float4* lds_item(const float4* base, int i) {
+    return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + __umul24((unsigned int)i, 16u * LDS_ITEM_F4));
+}
 
 // ALL_LDS: every interior node and every (leaf-ordered) intersection record is staged in LDS --
 // small scenes -- so neither the walk nor the leaf phase has a global-memory path.
@@ -592,7 +605,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             if (cur >= 0) {
                 float4 q0, q1, q2, q3;
                 if (ALL_LDS || cur < staged) {
-                    const float4* np = lds_nodes + LDS_ITEM_F4 * cur;
+                    const float4* np = lds_item(lds_nodes, cur);
                     q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
                 } else {
                     const float4* np = sc.nodes + 4 * (size_t)cur;
@@ -640,7 +653,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     const int k = valid ? leaf_k + j : leaf_n - 1;
                     if (COUNT) n_tri += valid ? 1 : 0;
                     if (COUNT) n_wave_rounds += lane == __ffsll((long long)lane_mask(true)) - 1 ? 1 : 0;
-                    const float4* rec = ALL_LDS ? lds_records + LDS_ITEM_F4 * lds_refs[off + 1 + k]
+                    const float4* rec = ALL_LDS ? lds_item(lds_records, lds_refs[off + 1 + k])
                                                 : sc.isect + 4 * (size_t)sc.refs[off + 1 + k];
                     triangle_round<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, valid, best);
                 }
@@ -650,7 +663,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     const bool valid = j == 0 || leaf_k + j < leaf_n;
                     if (j > 0 && lane_mask(valid) == 0ull) break;
                     const int k = valid ? leaf_k + j : leaf_n - 1;
-                    const float4* rec = ALL_LDS ? lds_records + LDS_ITEM_F4 * (off + k) : sc.isect + 4 * (size_t)(off + k);
+                    const float4* rec = ALL_LDS ? lds_item(lds_records, off + k) : sc.isect + 4 * (size_t)(off + k);
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                     if (j == 0) leaf_n = leaf_k == 0 ? __float_as_int(r1.w) : leaf_n;  // a leaf's first record carries its size
                     if (COUNT) n_tri += valid ? 1 : 0;

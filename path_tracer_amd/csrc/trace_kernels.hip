@@ -30,7 +30,7 @@ std::mutex g_scratch_mutex;
 // launch has `n_regions` queue regions of `cap_block` entries, whose ray counts are read from device memory
 // (written by the previous stage, so the host never waits for a count) or follow from n_fixed.
 template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS, bool POOL>
-__global__ __launch_bounds__(256) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
+__global__ __launch_bounds__(256, 6) void trace_kernel(SceneGpu sc, const float4* __restrict__ ray_o,
                                                     const float4* __restrict__ ray_d, float4* __restrict__ hit,
                                                     const int* __restrict__ n_ptr, int n_fixed, int cap_block, int n_regions,
                                                     int* __restrict__ cursors, unsigned long long* __restrict__ block_stats,
