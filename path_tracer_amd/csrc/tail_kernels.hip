@@ -83,7 +83,7 @@ hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchG
     const int refill = asked ? (asked > 64 ? 64 : asked) : (fits_lds(scene) ? 32 : 8);  // a wave never has more than 64 idle lanes
     // node-phase leave rule: 0 = per scene (4 in LDS, else 1), 15 = stay until nobody walks
     const int k_bits = (mode >> 4) & 15;
-    const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 0 : k_bits);
+    const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 65 : k_bits);  // 65: with at least one lane walking the product exceeds any count of waiting lanes
     const int leave_k = k | (refill << 8);
 #define PT_ARGS cfg, scene, batch, level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k
     if (kd) {

@@ -600,7 +600,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         while (true) {
             const int walking = __popcll(lane_mask(cur >= 0));
             if (walking == 0) break;
-            if (leave_k > 0 && walking * leave_k < __popcll(lane_mask((unsigned int)cur > (unsigned int)RAY_DONE))) break;
+            if (walking * leave_k < __popcll(lane_mask((unsigned int)cur > (unsigned int)RAY_DONE))) break;
             if (COUNT) n_wave_steps += lane == 0 ? 1 : 0;
             if (cur >= 0) {
                 float4 q0, q1, q2, q3;

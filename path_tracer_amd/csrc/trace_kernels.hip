@@ -126,7 +126,7 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
     const int refill = asked ? (asked > 64 ? 64 : asked) : (fits_lds(scene) ? 32 : 8);  // a wave never has more than 64 idle lanes
     // node-phase leave rule: 0 = per scene (4 in LDS, else 1), 15 = stay until nobody walks
     const int k_bits = (mode >> 4) & 15;
-    const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 0 : k_bits);
+    const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 65 : k_bits);  // 65: with at least one lane walking the product exceeds any count of waiting lanes
     const int leave_k = k | (refill << 8);
 #define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats, leave_k
     if ((mode & 8) != 0 || cap_block > POOL_MAX_REGION) {  // every workgroup traces its own region (always with the dynamic refill)
