@@ -60,7 +60,7 @@ class FrameReducer:
         slot = self.frame_index % len(self.deltas)
         buf = self.deltas[slot]
         work = True
-        if self.world > 1:
+        if self.dist.is_initialized():  # also with one rank: the collective call itself runs (RCCL has nothing to move then)
             if buf.is_cuda and self.dist.get_backend(self.group) == "gloo":
                 # rehearsal path (gloo reduces host tensors only): stage through host memory
                 host = buf.cpu()
