@@ -378,8 +378,10 @@ def summarise_counters(cc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed frames (default 200, 12 for the sponza workload: with a few dozen 2-ms frames the empty pipeline "
+                         "at both ends of the timed region costs 2-3 %%)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frames before (default 10, 2 for the sponza workload)")
     ap.add_argument("--workload", default="cornellbox", choices=sorted(WORKLOADS))
     ap.add_argument("--obj", default=None, help="render this .obj instead of a named workload")
     ap.add_argument("--hdr", default=None)
@@ -409,6 +411,10 @@ def main():
     args.width = args.width or dw
     args.height = args.height or dh
     args.spp = args.spp or dspp
+    if args.steps is None:
+        args.steps = 12 if args.workload == "sponza" else 200
+    if args.warmup is None:
+        args.warmup = 2 if args.workload == "sponza" else 10
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

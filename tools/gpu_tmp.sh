@@ -1,11 +1,15 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-export PT_AMD_LIB=$PWD/ab_libs/libpt_timeline.so
-{
-echo "== workgroups on their own regions (PT_OPT_TRAVERSAL bit 3), BVH"; timeout -k 10 200 python3 tools/wg_timeline.py cornellbox.obj bvh 5800000 OPT_TRAVERSAL=9 | grep -v "^xcd" || exit 1
-echo; echo "== shared pools (pt_trace_batch's default), BVH"; timeout -k 10 200 python3 tools/wg_timeline.py cornellbox.obj bvh 5800000 | grep -v "^xcd" || exit 1
-echo; echo "== own regions, kd-tree"; timeout -k 10 200 python3 tools/wg_timeline.py cornellbox.obj kd 5800000 OPT_TRAVERSAL=9 | grep -v "^xcd" || exit 1
-echo; echo "== shared pools, kd-tree"; timeout -k 10 200 python3 tools/wg_timeline.py cornellbox.obj kd 5800000 | grep -v "^xcd" || exit 1
-} > gpurun_out/wg_timeline.txt 2>&1
-echo rc=$?; grep -E "==|launch by|wave-time|at the peak" gpurun_out/wg_timeline.txt
+s=$(date +%s)
+timeout -k 10 600 python3 bench.py > gpurun_out/bench_def.json 2> gpurun_out/bench_def.err || { tail gpurun_out/bench_def.err; exit 1; }
+e=$(date +%s); echo "default bench wall $((e-s)) s"
+python3 -c "
+import json
+d=json.loads(open('gpurun_out/bench_def.json').read().strip().splitlines()[-1]); r=d['roofline']
+print(d['value'], d['ms_per_step'], d['steps'], d['warmup'], r['frac'], r['avg_launch_ms'], r['alone']['frac'], d['kd_tree'], {k:v['Mrays/s'] for k,v in d['sponza'].items() if isinstance(v,dict)}, d['cpu_baseline']['value'])"
+timeout -k 10 300 python3 bench.py --workload sponza --no-pmc --no-cpu-baseline > gpurun_out/bench_sp.json 2> gpurun_out/bench_sp.err || { tail gpurun_out/bench_sp.err; exit 1; }
+python3 -c "
+import json
+d=json.loads(open('gpurun_out/bench_sp.json').read().strip().splitlines()[-1]); r=d['roofline']
+print(d['value'], d['ms_per_step'], d['steps'], r['bound'], r['frac'], r['fractions'])"
