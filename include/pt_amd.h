@@ -95,10 +95,10 @@ enum {
     PT_OPT_TREE_IN_LDS = 14,  /* read only: 1 when the built scene's whole tree and its intersection records are staged in LDS by
                                  the trace kernels (small scenes: the walk then has no global-memory path, so instruction
                                  issue and not memory bandwidth bounds it) */
-    PT_OPT_STREAMS = 13       /* batches in flight, 1..4.  Unless set, pt_build chooses: 3, or 2 for a scene whose tree is walked
-                                 in LDS and has no translucent surface (a third batch gains nothing there); and 2 from the
-                                 moment the context joins a group or is given an external per-frame buffer, which leaves a
-                                 hardware queue to the collective library.  Consecutive batches (frames, when a frame is one
+    PT_OPT_STREAMS = 13       /* batches in flight, 1..4.  Unless set, chosen when a frame is queued: 3, or 2 for frames of
+                                 more than 4 Mi samples of a scene whose tree is walked in LDS and has no translucent surface
+                                 (a third batch gains nothing there); and 2 from the moment the context joins a group or is
+                                 given an external per-frame buffer, which leaves a hardware queue to the collective library.  Consecutive batches (frames, when a frame is one
                                  batch) run on internal streams with queues of their own, so the thinly populated late
                                  levels of one overlap the early levels of the next; the kernels that touch the image
                                  (accumulate, resolve, clear) stay on the context's stream in program order, so the image
@@ -209,6 +209,11 @@ int pt_total_samples(PtContext* ctx);
  * resolves again.  A caller that hands external buffers to a collective and renders scenes whose
  * paths fork heavily calls this before the collective. */
 int pt_synchronize(PtContext* ctx);
+/* Returns when at most `keep` of the frames queued by pt_render / pt_render_split are still unfinished (0 = all have
+ * ended), leaving the others running: a frame loop that shows no pixels paces itself with this instead of draining the
+ * GPU every frame as Scene::Pathtrace's join does (src/cs488.h:1893-1895).  Unlike pt_synchronize it does not render
+ * overflowed batches again; pt_synchronize / pt_download before the pixels are read stay as they are. */
+int pt_wait_frames(PtContext* ctx, int keep);
 /* which: 0 = accumulation buffer, 1 = frame buffer.  Synchronises. */
 int pt_download(PtContext* ctx, int which, float* dst);
 /* Device address of the accumulation buffer (W*H*3 floats), for a collective over it. */

@@ -33,7 +33,7 @@ TRACE_STATIC_MAX_RAYS = 1 << 17
 
 # every symbol include/pt_amd.h declares
 EXPORTS = [
-    "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_set_option", "pt_get_option",
+    "pt_create", "pt_destroy", "pt_last_error", "pt_set_stream", "pt_set_option", "pt_get_option", "pt_wait_frames",
     "pt_load_obj", "pt_single_triangle", "pt_load_env", "pt_set_mesh", "pt_set_materials", "pt_set_texture",
     "pt_set_env", "pt_num_triangles", "pt_num_materials", "pt_get_mesh", "pt_get_material", "pt_get_texture",
     "pt_get_env", "pt_build", "pt_get_tree", "pt_set_camera", "pt_set_resolution", "pt_reset", "pt_render",
@@ -286,6 +286,10 @@ class Scene:
 
     def accum_device_ptr(self):
         return self.L.pt_accum_device_ptr(self.h)
+
+    def wait_frames(self, keep=0):
+        """Blocks until at most `keep` of the frames queued by pathtrace / pathtrace_split are unfinished."""
+        self._check(self.L.pt_wait_frames(self.h, int(keep)))
 
     def use_external_accum(self, device_ptr):
         self._check(self.L.pt_use_external_accum(self.h, C.c_void_p(device_ptr)))

@@ -19,7 +19,10 @@
 // --obj-polygons (faces with more than three vertices as triangle fans, negative indices; the
 // reference reads three vertices per face, src/cs488.h:1059), --gpus N (the frame's samples are split over
 // GPUs device .. device+N-1 of this node and summed onto the first with one RCCL reduce per frame, in place of the
-// reference's column-strip threads, src/cs488.h:1885-1895; the output lines stay the same).
+// reference's column-strip threads, src/cs488.h:1885-1895; the output lines stay the same), --drain-frames (wait for
+// every frame before the next is queued, as the reference's join at src/cs488.h:1893-1895 does; without it a frame
+// whose pixels nobody reads that frame -- no recording, no --sequence -- only waits until the frame a few before it
+// has ended, so consecutive frames overlap on the GPU and the printed seconds are the time between frames).
 //
 // Window input is replaced by a script (--script FILE), one event per line, applied where the
 // reference polls events, i.e. before the frame with that index is rendered (src/cs488.h:2283):
@@ -49,7 +52,7 @@ struct Options {
     std::vector<std::string> positional;
     int width = 512, height = 384, spp = 10, frames = 10, accel = PT_ACCEL_KD, device = 0, max_level = 15;
     int gpus = 0;  // 0: one context, no group; N >= 1: a group of N contexts (N = 1 still goes through the reduce)
-    bool progressive = true, stats = false;
+    bool progressive = true, stats = false, drain_frames = false;
     bool have_seed = false;
     uint64_t seed = 0;
     float eye[3] = {0.0f, 0.0f, 1.5f}, lookat[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
@@ -120,7 +123,7 @@ void usage() {
     fprintf(stderr,
             "usage: CS488 <scene.obj> [probe.hdr] [--accel kd|bvh] [--spp N] [--width W --height H] [--frames N]\n"
             "             [--out frame.png|frame.pfm] [--no-progressive] [--max-level N] [--eye x y z] [--lookat x y z]\n"
-            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--gpus N] [--stats] [--headless]\n"
+            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--gpus N] [--stats] [--headless] [--drain-frames]\n"
             "             [--script events.txt] [--sequence PREFIX] [--obj-polygons]\n");
 }
 
@@ -131,6 +134,7 @@ bool parse(int argc, const char* argv[], Options& o) {
         if (a.rfind("--", 0) != 0) { o.positional.push_back(a); continue; }
         if (a == "--headless") continue;  // the only mode there is
         else if (a == "--stats") o.stats = true;
+        else if (a == "--drain-frames") o.drain_frames = true;
         else if (a == "--no-progressive") o.progressive = false;
         else if (a == "--accel") { if (!need(i, 1)) return false; std::string v = argv[++i]; if (v == "kd") o.accel = PT_ACCEL_KD; else if (v == "bvh") o.accel = PT_ACCEL_BVH; else { usage(); return false; } }
         else if (a == "--spp") { if (!need(i, 1)) return false; o.spp = atoi(argv[++i]); }
@@ -269,6 +273,8 @@ int main(int argc, const char* argv[]) {
     bool recording = false, quit = false;
     double total_seconds = 0.0;
     int frames_done = 0;
+    uint64_t in_flight = 2;  // frames the context keeps in flight: as many may be queued ahead of the one waited for
+    if (!cs.group) (void)pt_get_option(ctx, PT_OPT_STREAMS, &in_flight);
     for (int frame = 0; frame < opt.frames && !quit; frame++) {
         auto t0 = std::chrono::high_resolution_clock::now();
         for (const Event& e : events) {
@@ -328,7 +334,8 @@ int main(int argc, const char* argv[]) {
         // Scene::Pathtrace, src/cs488.h:1878-1897: on one GPU, or split by samples over the group with one reduce
         rc = cs.group ? pt_group_render(cs.group, opt.spp) : pt_render(ctx, opt.spp);
         if (rc == PT_OK) rc = cs.group ? pt_group_synchronize(cs.group) : PT_OK;
-        if (rc == PT_OK) rc = pt_synchronize(ctx);
+        const bool pixels_read = recording || !opt.sequence.empty();
+        if (rc == PT_OK) rc = (cs.group || opt.drain_frames || pixels_read) ? pt_synchronize(ctx) : pt_wait_frames(ctx, (int)in_flight);
         if (rc != PT_OK) return die(cs, "pt_render", rc);
         std::cout << pt_total_samples(ctx) << std::endl;  // src/cs488.h:1896
         if (recording || !opt.sequence.empty()) {
@@ -347,6 +354,11 @@ int main(int argc, const char* argv[]) {
         std::cout << seconds << std::endl;  // src/cs488.h:2322
     }
 
+    {  // what is still in flight belongs to the run's time
+        auto t0 = std::chrono::high_resolution_clock::now();
+        if ((rc = pt_synchronize(ctx)) != PT_OK) return die(cs, "pt_synchronize", rc);
+        total_seconds += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::high_resolution_clock::now() - t0).count();
+    }
     if (!opt.out.empty() && (rc = save_frame(ctx, opt.out)) != PT_OK) return die(cs, "saving the frame", rc);
     if (opt.stats) {
         uint64_t cnt[PT_CNT_COUNT] = {};

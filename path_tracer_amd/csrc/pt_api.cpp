@@ -141,7 +141,8 @@ struct PtContext {
     PtGroup* group = nullptr;             // set while the context is a member of a multi-GPU group
     Lane lanes[MAX_LANES];
     int n_lanes = 3;                      // batches in flight (PT_OPT_STREAMS)
-    bool lanes_auto = true;               // not set by the caller: chosen per scene in pt_build; two once a collective library shares the GPU's queues
+    bool lanes_auto = true;               // not set by the caller: chosen per scene and frame size (choose_lanes); two once a collective library shares the GPU's queues
+    size_t lanes_for_frame = 0;           // samples per frame the choice was made for (0 = not made)
     bool lanes_checked = false;           // the lanes' streams have been probed for running side by side
     int lane_stream_swaps = 0;            // streams replaced by that probe
     DeviceBuffer<unsigned long long> d_totals;
@@ -149,6 +150,7 @@ struct PtContext {
     DeviceBuffer<int> d_cursors;          // pool cursors of pt_trace_batch's launch, cleared before each
     DeviceBuffer<int> d_batch_flags;      // FLAG_RING overflow flags, one per batch in flight
     std::vector<IssuedBatch> issued;      // batches whose flags have not been looked at yet
+    std::deque<hipEvent_t> frame_ends;    // one event per frame queued by pt_render / pt_render_split, oldest first (pt_wait_frames)
     uint64_t batch_seq = 0, repaired_batches = 0;
     size_t batch_hint = 0;                // samples of the largest batch of the frame being rendered
     uint64_t batch_rays = 0;  // rays traced through pt_trace_batch
@@ -217,6 +219,21 @@ hipEvent_t take_event(PtContext* c) {
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) e = nullptr;  // the span is then left out (ScopedTimer)
     return e;
+}
+
+// Marks the end of a frame on the context's stream for pt_wait_frames.  At most 64 marks are kept: a caller
+// that never waits loses the oldest ones to a wait here, which is long over by then.
+int mark_frame_end(PtContext* c) {
+    while (c->frame_ends.size() >= 64) {
+        (void)hipEventSynchronize(c->frame_ends.front());
+        c->event_pool.push_back(c->frame_ends.front());
+        c->frame_ends.pop_front();
+    }
+    hipEvent_t e = take_event(c);
+    if (!e) return fail(c, PT_ERR_HIP, "no event for the end of the frame");
+    PT_HIP(c, hipEventRecord(e, c->stream));
+    c->frame_ends.push_back(e);
+    return PT_OK;
 }
 
 struct ScopedTimer {
@@ -438,17 +455,7 @@ int flatten_and_upload(PtContext* c) {
         if (!(hm2.opacity >= 1.0f - PT_EPSILON)) s.fixed_radiance = 1;  // the alpha fork of src/cs488.h:2038
     s.shading_kind = (other || (metal && glass)) ? 0 : (glass ? 3 : (metal ? 4 : (plain ? 2 : 1)));
     choose_lds_nodes(c);
-    if (c->lanes_auto && !c->ext_accum && !c->group) {
-        // Batches in flight, unless the caller chose: three -- except for a scene whose tree is walked in LDS and whose
-        // paths do not fork, where the third brings nothing (cornellbox: +0.3 %, its kd-tree -1 %; teapot +14 %,
-        // cornellbox-alpha +5 %, a 210 k-triangle courtyard +4 %) and costs a lane's queues.
-        const int lanes = (s.lds_nodes >= s.n_nodes && !s.fixed_radiance) ? 2 : 3;
-        if (lanes != c->n_lanes) {
-            if (c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
-            c->n_lanes = lanes;
-            c->lanes_checked = false;
-        }
-    }
+    c->lanes_for_frame = 0;  // batches in flight are chosen again at the next frame (choose_lanes)
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)
         for (int k = 0; k < 6; k++)
@@ -727,6 +734,8 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
 int settle(PtContext* c) {
     PT_HIP(c, hipSetDevice(c->device));  // the caller's thread may have another device current
     PT_HIP(c, hipStreamSynchronize(c->stream));
+    for (hipEvent_t e : c->frame_ends) c->event_pool.push_back(e);  // every frame queued so far has ended
+    c->frame_ends.clear();
     drain_spans(c);
     bool repaired = false;
     std::vector<IssuedBatch> todo;
@@ -770,11 +779,32 @@ int settle(PtContext* c) {
     return PT_OK;
 }
 
+// Batches in flight, unless the caller chose: three -- except for frames of more than 4 Mi samples of a scene whose
+// tree is walked in LDS and whose paths do not fork, where the third brings nothing (cornellbox at 1024 x 1024 x 10:
+// +0.3 %, its kd-tree -1 %; at the reference's 512 x 384 x 10: +15 %; teapot +14 %, cornellbox-alpha +5 %, a
+// 210 k-triangle courtyard +4 %) and costs a lane's queues.
+int choose_lanes(PtContext* c, size_t frame_samples) {
+    if (!c->lanes_auto || c->ext_accum || c->group || c->lanes_for_frame == frame_samples) return PT_OK;
+    c->lanes_for_frame = frame_samples;
+    const SceneGpu& s = c->scene;
+    const int lanes = (s.lds_nodes >= s.n_nodes && !s.fixed_radiance && frame_samples > ((size_t)4 << 20)) ? 2 : 3;
+    if (lanes != c->n_lanes) {
+        if (c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+        c->n_lanes = lanes;
+        c->lanes_checked = false;
+    }
+    return PT_OK;
+}
+
 int render_range(PtContext* c, int spp_frame, int first, int count) {
     if (!c->built) return fail(c, PT_ERR_NOT_READY, "pt_build has not been called");
     if (c->width <= 0 || c->height <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
     if (spp_frame <= 0 || first < 0 || count < 0 || first + count > spp_frame) return fail(c, PT_ERR_INVALID_ARG, "bad sample range");
     PT_HIP(c, hipSetDevice(c->device));
+    {
+        const int rc = choose_lanes(c, (size_t)c->width * c->height * (size_t)count);
+        if (rc != PT_OK) return rc;
+    }
     const int base = c->total_samples;  // global index of this frame's first sample
     c->total_samples += spp_frame;      // src/cs488.h:1882
     const size_t n_pixels = (size_t)c->width * c->height;
@@ -854,6 +884,7 @@ void pt_destroy(PtContext* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drain_spans(c);
+    for (hipEvent_t e : c->frame_ends) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     c->d_nodes.release(); c->d_isect.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
     c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
@@ -1162,7 +1193,9 @@ int pt_render(PtContext* c, int spp) {
     if (!c) return PT_ERR_INVALID_ARG;
     int rc = render_range(c, spp, 0, spp);
     if (rc != PT_OK) return rc;
-    return pt_resolve(c);
+    rc = pt_resolve(c);
+    if (rc != PT_OK) return rc;
+    return mark_frame_end(c);
     PT_CATCH(c)
 }
 
@@ -1170,7 +1203,9 @@ int pt_render_split(PtContext* c, int spp_frame, int first, int count) {
     PT_TRY
     if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c) return PT_ERR_INVALID_ARG;
-    return render_range(c, spp_frame, first, count);
+    const int rc = render_range(c, spp_frame, first, count);
+    if (rc != PT_OK) return rc;
+    return mark_frame_end(c);
     PT_CATCH(c)
 }
 
@@ -1191,6 +1226,21 @@ int pt_synchronize(PtContext* c) {
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
     return settle(c);
+    PT_CATCH(c)
+}
+
+// Returns when at most `keep` of the frames queued so far are unfinished.  Unlike pt_synchronize it leaves the
+// rest of the queue running and does not look at overflowed batches.
+int pt_wait_frames(PtContext* c, int keep) {
+    PT_TRY
+    if (!c || keep < 0) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    while ((int)c->frame_ends.size() > keep) {
+        PT_HIP(c, hipEventSynchronize(c->frame_ends.front()));
+        c->event_pool.push_back(c->frame_ends.front());
+        c->frame_ends.pop_front();
+    }
+    return PT_OK;
     PT_CATCH(c)
 }
 

@@ -33,7 +33,6 @@ stream = torch.cuda.current_stream()
 ranks = []
 for r in range(2):
     s = load_gpu_scene("cornellbox.obj", orc.BVH)
-    assert s.get_option(pta.OPT_STREAMS) == 2  # cornellbox: walked in LDS, no translucent surface
     s.set_stream(stream.cuda_stream)
     s.set_resolution(W, H)
     deltas = [torch.full((W * H * 3,), 7.0, dtype=torch.float32, device="cuda") for _ in range(2)]

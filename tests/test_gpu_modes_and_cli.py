@@ -163,6 +163,45 @@ def test_cli_stdout_protocol(gpu_device, tmp_path):
     assert r.stdout.splitlines()[-2] == "2" and "Mrays/s" in r.stderr
 
 
+def test_cli_frames_overlap_unless_asked_to_drain(gpu_device, tmp_path):
+    """Without a reader of the pixels the frame loop only waits for the frame a few before (pt_wait_frames); with
+    --drain-frames it waits for every frame as the reference's join does.  Same lines, same image."""
+    obj = scene_path("cornellbox.obj")
+    outs = []
+    for extra in ([], ["--drain-frames"]):
+        out = str(tmp_path / ("frame%d.pfm" % len(outs)))
+        r = run_cli(obj, "--accel", "bvh", "--frames", "9", "--spp", "3", "--width", "80", "--height", "60", "--out", out, *extra)
+        assert r.returncode == 0, r.stderr
+        body = r.stdout.splitlines()[4:22]
+        assert body[0::2] == [str(3 * k) for k in range(1, 10)] and all(float(x) > 0 for x in body[1::2])
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_wait_frames(gpu_device):
+    """pt_wait_frames(keep) returns once at most `keep` queued frames are unfinished; waiting for all of them leaves
+    the image a frame-by-frame run gives."""
+    def render(pace):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        s.set_resolution(96, 72)
+        for _ in range(7):
+            s.pathtrace(4)
+            if pace == "each":
+                s.synchronize()
+            elif pace == "keep2":
+                s.wait_frames(2)
+        s.wait_frames(0)
+        s.wait_frames(5)   # nothing left to wait for
+        img = s.frame_buffer()
+        with pytest.raises(Exception):
+            s.wait_frames(-1)
+        s.close()
+        return img
+    a, b, c = render("each"), render("keep2"), render("none")
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
 def test_cli_fallbacks(gpu_device, tmp_path):
     r = run_cli("--frames", "1", "--width", "16", "--height", "12")
     assert r.returncode == 0
@@ -285,12 +324,15 @@ def test_frames_in_flight_do_not_change_the_image(gpu_device, obj, accel):
 
 @pytest.mark.gpu
 def test_batches_in_flight_are_chosen_per_scene(gpu_device):
-    """Unless the caller sets PT_OPT_STREAMS, pt_build chooses: two batches in flight for a scene walked in LDS
-    without translucent surfaces, three otherwise; a context whose frames go into a collective (an external
-    per-frame buffer) keeps two; a value the caller set is left alone."""
-    for obj, want in (("cornellbox.obj", 2), ("cornellbox-alpha.obj", 3), ("teapot.obj", 3)):
+    """Unless the caller sets PT_OPT_STREAMS it is chosen when a frame is queued: two batches in flight for large
+    frames of a scene walked in LDS without translucent surfaces, three otherwise; a context whose frames go into a
+    collective (an external per-frame buffer) keeps two; a value the caller set is left alone."""
+    for obj, w, h, want in (("cornellbox.obj", 1024, 1024, 2), ("cornellbox.obj", 512, 384, 3), ("cornellbox-alpha.obj", 1024, 1024, 3),
+                            ("teapot.obj", 1024, 1024, 3)):
         s = load_gpu_scene(obj, pta.BVH)
-        assert s.get_option(pta.OPT_STREAMS) == want, obj
+        s.set_resolution(w, h)
+        s.pathtrace(10)
+        assert s.get_option(pta.OPT_STREAMS) == want, (obj, w, h)
         s.close()
     s = pta.Scene(gpu_device)
     s.set_option(pta.OPT_STREAMS, 4)
