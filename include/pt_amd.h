@@ -81,8 +81,9 @@ enum {
                                  entirely in LDS, else 8) */
     PT_OPT_TAIL_LEVEL = 9,    /* bounce levels from this one on are finished by one fused launch in which every
                                  workgroup alternates trace and shade on its own queue region (default 255 = per scene: 6,
-                                 the level after Russian roulette starts, src/cs488.h:2153, for a tree held in LDS (1 for such a
-                                 kd-tree in a plain Lambertian scene rendered one batch at a time), else 8; 0 = one launch per level and stage).
+                                 the level after Russian roulette starts, src/cs488.h:2153, for a tree held in LDS (2 for
+                                 batches of at most 4 Mi samples; 1 for such a kd-tree in a plain Lambertian scene rendered one
+                                 batch at a time), else 8; 0 = one launch per level and stage).
                                  Same device code either way, so the image does not depend on it */
     PT_OPT_BUILD_THREADS = 10,/* host threads pt_build may use for the tree (0 = all, default; 1 = none extra).  Large
                                  subtrees near the root are built concurrently and spliced in at their sequential
@@ -144,7 +145,10 @@ int pt_create(int device, PtContext** out);
 /* (A member of a group is left alone: destroy the group first.) */
 void pt_destroy(PtContext* ctx);
 const char* pt_last_error(PtContext* ctx);
-/* Use an existing HIP stream (hipStream_t as void*) for every launch instead of the context's own. */
+/* The stream (hipStream_t as void*) on which the context orders its work: the kernels that touch the image run on
+ * it, the rest of a batch on internal streams joined to it by events.  Until this is called it is the device's
+ * null stream (which holds one of the process's four hardware queues anyway; a further stream would take one
+ * from the batches in flight). */
 int pt_set_stream(PtContext* ctx, void* hip_stream);
 int pt_set_option(PtContext* ctx, int option, uint64_t value);
 int pt_get_option(PtContext* ctx, int option, uint64_t* value);

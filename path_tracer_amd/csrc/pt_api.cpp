@@ -689,7 +689,10 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     const bool in_lds = c->scene.lds_nodes >= c->scene.n_nodes;
     const bool light_shading = c->scene.shading_kind == 2;  // SHADE_PLAIN: the fused kernel keeps the walk's occupancy
     // (with a second batch in flight the launch gaps that the early hand-over saved are filled anyway: 6 is 3 % faster then)
-    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : 6) : 8) : c->tail_level;
+    // a small batch (the reference's own 512 x 384 x 10) is handed over after the first bounce: its per-level launches are too
+    // short to fill the chip (14.0 -> 15.0 Grays/s with a BVH, 9.4 -> 9.9 with a kd-tree; 3 and later are slower again)
+    const bool small_batch = b.n_slots <= (4 << 20);
+    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : (small_batch ? 2 : 6)) : 8) : c->tail_level;
     const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
     const int split = fuse ? tail : levels;
     for (int level = 0; level < split; level++) {
@@ -789,7 +792,7 @@ int choose_lanes(PtContext* c, size_t frame_samples) {
     const SceneGpu& s = c->scene;
     const int lanes = (s.lds_nodes >= s.n_nodes && !s.fixed_radiance && frame_samples > ((size_t)4 << 20)) ? 2 : 3;
     if (lanes != c->n_lanes) {
-        if (c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+        if (c->device != PT_DEVICE_NONE) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
         c->n_lanes = lanes;
         c->lanes_checked = false;
     }
@@ -854,8 +857,12 @@ int pt_create(int device, PtContext** out) {
     PtContext* c = new (std::nothrow) PtContext();
     if (!c) return PT_ERR_NO_MEMORY;
     c->device = device;
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return PT_ERR_HIP; }
-    c->own_stream = true;
+    // The context's stream is the device's null stream until pt_set_stream names another: a process has four
+    // hardware queues per GPU and the null stream holds one of them anyway, so a stream of the context's own would
+    // leave only two for the lanes (measured at 512 x 384: 0.72 ms per frame with an own stream and three lanes
+    // on the four queues that five streams share, 0.54 with the null stream and three lanes).
+    c->stream = nullptr;
+    c->own_stream = false;
     hipDeviceProp_t prop;
     // eight 256-lane workgroups per CU are resident at once with the kernels' register and LDS use
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) { c->cus = prop.multiProcessorCount; c->blocks = prop.multiProcessorCount * 8; }
@@ -882,7 +889,7 @@ void pt_destroy(PtContext* c) {
     if (c->group) return;  // destroy the group first: it holds streams and buffers of this context
     if (c->device == PT_DEVICE_NONE) { delete c; return; }
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->device != PT_DEVICE_NONE) (void)hipStreamSynchronize(c->stream);
     drain_spans(c);
     for (hipEvent_t e : c->frame_ends) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -957,7 +964,7 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             c->build_threads = (int)value; break;
         case PT_OPT_STREAMS:
             if (value < 1 || value > MAX_LANES) return fail(c, PT_ERR_INVALID_ARG, "between 1 and 4 batches in flight");
-            if (c->device != PT_DEVICE_NONE && c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+            if (c->device != PT_DEVICE_NONE) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
             c->n_lanes = (int)value; c->lanes_auto = false; c->lanes_checked = false; break;
         case PT_OPT_TAIL_LEVEL:
             if (value > 64 && value != 255) return fail(c, PT_ERR_INVALID_ARG, "tail level above 64");
@@ -1265,7 +1272,7 @@ void* pt_accum_device_ptr(PtContext* c) { return c ? (void*)c->accum_ptr() : nul
 // context whose number of lanes the caller has not chosen keeps two from then on.
 static int leave_a_queue_for_the_collective(PtContext* c) {
     if (!c->lanes_auto || c->n_lanes <= 2) return PT_OK;
-    if (c->stream) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+    if (c->device != PT_DEVICE_NONE) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
     c->n_lanes = 2;
     c->lanes_checked = false;
     return PT_OK;
