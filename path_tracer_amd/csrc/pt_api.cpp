@@ -692,7 +692,9 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     // a small batch (the reference's own 512 x 384 x 10) is handed over after the first bounce: its per-level launches are too
     // short to fill the chip (14.0 -> 15.0 Grays/s with a BVH, 9.4 -> 9.9 with a kd-tree; 3 and later are slower again)
     const bool small_batch = b.n_slots <= (4 << 20);
-    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : (small_batch ? 2 : 6)) : 8) : c->tail_level;
+    // (a tree in memory: 4, and 2 for a small batch as well -- teapot 512 x 384: 5.8 -> 7.5 Grays/s, its kd-tree 2.8 -> 3.8; at 1024 x 1024
+    // 11.0 -> 11.7; the 210 k-triangle courtyard +1.4 %; the deep levels of an open scene are nearly empty launches otherwise)
+    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : (small_batch ? 2 : 6)) : (small_batch ? 2 : 4)) : c->tail_level;
     const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
     const int split = fuse ? tail : levels;
     for (int level = 0; level < split; level++) {
