@@ -199,6 +199,8 @@ def make_scene(pta, args, device, accel):
         s.set_option(pta.OPT_TAIL_LEVEL, args.tail_level)
     if args.blocks_per_cu is not None:
         s.set_option(pta.OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    if getattr(args, "max_batch", None) is not None:
+        s.set_option(pta.OPT_MAX_BATCH, args.max_batch)
     if args.streams is not None:
         s.set_option(pta.OPT_STREAMS, args.streams)
     s.set_resolution(args.width, args.height)
@@ -296,7 +298,7 @@ def sponza_record(pta, args, device, stream_handle):
     sub = copy.copy(args)
     sub.workload, sub.obj, sub.hdr = "sponza", None, None
     sub.width, sub.height, sub.spp = DEFAULT_SHAPE["sponza"]
-    sub.lds_nodes = sub.traversal = sub.tail_level = sub.blocks_per_cu = sub.streams = None
+    sub.lds_nodes = sub.traversal = sub.tail_level = sub.blocks_per_cu = sub.streams = sub.max_batch = None
     for name, accel in (("bvh", pta.BVH), ("kd", pta.KD)):
         sub.accel = name
         s = make_scene(pta, sub, device, accel)
@@ -393,6 +395,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=None, help="PT_OPT_BLOCKS_PER_CU")
     ap.add_argument("--streams", type=int, default=None, help="PT_OPT_STREAMS: batches (frames) in flight, 1..4")
     ap.add_argument("--tail-level", type=int, default=None, help="PT_OPT_TAIL_LEVEL (0 = one launch per level)")
+    ap.add_argument("--max-batch", type=int, default=None, help="PT_OPT_MAX_BATCH: most camera samples of one wavefront batch")
     ap.add_argument("--traversal", type=lambda v: int(v, 0), default=None, help="PT_OPT_TRAVERSAL bits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kd", action="store_true", help="skip the short kd-tree comparison run")

@@ -143,6 +143,7 @@ struct PtContext {
     int n_lanes = 3;                      // batches in flight (PT_OPT_STREAMS)
     bool lanes_auto = true;               // not set by the caller: chosen per scene and frame size (choose_lanes); two once a collective library shares the GPU's queues
     size_t lanes_for_frame = 0;           // samples per frame the choice was made for (0 = not made)
+    size_t frame_samples = 0;             // samples of the frame being queued (this context's share)
     bool lanes_checked = false;           // the lanes' streams have been probed for running side by side
     int lane_stream_swaps = 0;            // streams replaced by that probe
     DeviceBuffer<unsigned long long> d_totals;
@@ -689,9 +690,9 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     const bool in_lds = c->scene.lds_nodes >= c->scene.n_nodes;
     const bool light_shading = c->scene.shading_kind == 2;  // SHADE_PLAIN: the fused kernel keeps the walk's occupancy
     // (with a second batch in flight the launch gaps that the early hand-over saved are filled anyway: 6 is 3 % faster then)
-    // a small batch (the reference's own 512 x 384 x 10) is handed over after the first bounce: its per-level launches are too
+    // the batches of a small frame (the reference's own 512 x 384 x 10) are handed over after the first bounce: their per-level launches are too
     // short to fill the chip (14.0 -> 15.0 Grays/s with a BVH, 9.4 -> 9.9 with a kd-tree; 3 and later are slower again)
-    const bool small_batch = b.n_slots <= (4 << 20);
+    const bool small_batch = c->frame_samples <= ((size_t)4 << 20) && c->frame_samples > 0;
     // (a tree in memory: 4, and 2 for a small batch as well -- teapot 512 x 384: 5.8 -> 7.5 Grays/s, its kd-tree 2.8 -> 3.8; at 1024 x 1024
     // 11.0 -> 11.7; the 210 k-triangle courtyard +1.4 %; the deep levels of an open scene are nearly empty launches otherwise)
     const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : (small_batch ? 2 : 6)) : (small_batch ? 2 : 4)) : c->tail_level;
@@ -806,8 +807,9 @@ int render_range(PtContext* c, int spp_frame, int first, int count) {
     if (c->width <= 0 || c->height <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
     if (spp_frame <= 0 || first < 0 || count < 0 || first + count > spp_frame) return fail(c, PT_ERR_INVALID_ARG, "bad sample range");
     PT_HIP(c, hipSetDevice(c->device));
+    c->frame_samples = (size_t)c->width * c->height * (size_t)count;
     {
-        const int rc = choose_lanes(c, (size_t)c->width * c->height * (size_t)count);
+        const int rc = choose_lanes(c, c->frame_samples);
         if (rc != PT_OK) return rc;
     }
     const int base = c->total_samples;  // global index of this frame's first sample
