@@ -83,7 +83,8 @@ enum {
                                  workgroup alternates trace and shade on its own queue region (default 255 = per scene: 6,
                                  the level after Russian roulette starts, src/cs488.h:2153, for a tree held in LDS (2 for
                                  frames of at most 4 Mi samples; 1 for such a kd-tree in a plain Lambertian scene rendered one
-                                 batch at a time), else 4 (2 for such small frames); 0 = one launch per level and stage).
+                                 batch at a time), else 4 (2 for such small frames), and earlier once an earlier batch has shown that a
+                                 level holds few rays; 0 = one launch per level and stage).
                                  Same device code either way, so the image does not depend on it */
     PT_OPT_BUILD_THREADS = 10,/* host threads pt_build may use for the tree (0 = all, default; 1 = none extra).  Large
                                  subtrees near the root are built concurrently and spliced in at their sequential

@@ -148,8 +148,9 @@ hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const 
                              unsigned long long* totals);
 // sums the per-workgroup queue counts of every level of a finished batch into totals
 // (nothing is added for a batch whose overflow flag is set: its pieces are tallied when they are rendered again)
+// (level_rays, if not null: the batch's rays per level, one word each, overwritten)
 hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, int tail_level, const int* overflow,
-                        unsigned long long* totals);
+                        unsigned long long* totals, unsigned long long* level_rays);
 hipError_t launch_resolve(const LaunchCfg& cfg, const float* accum, float* frame, int n_pixels, int total_samples);
 hipError_t launch_clear(const LaunchCfg& cfg, float* buf, size_t n);
 hipError_t launch_add(const LaunchCfg& cfg, float* dst, const float* src, size_t n);  // dst += src

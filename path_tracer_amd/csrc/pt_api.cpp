@@ -144,6 +144,16 @@ struct PtContext {
     bool lanes_auto = true;               // not set by the caller: chosen per scene and frame size (choose_lanes); two once a collective library shares the GPU's queues
     size_t lanes_for_frame = 0;           // samples per frame the choice was made for (0 = not made)
     size_t frame_samples = 0;             // samples of the frame being queued (this context's share)
+    // Rays per bounce level of an earlier batch, read back without a wait (run_batch): where the fused tail takes over
+    // follows from them once they are there.
+    enum { LEVEL_WORDS = 80 };
+    DeviceBuffer<unsigned long long> d_level_rays;
+    unsigned long long* h_level_rays = nullptr;   // pinned
+    hipEvent_t level_copied = nullptr;
+    bool level_copy_pending = false;
+    int level_copy_slots = 0, level_copy_levels = 0;   // batch the pending copy describes
+    std::vector<unsigned long long> level_rays;      // the last profile that arrived ...
+    int level_rays_slots = 0;                        // ... and the batch size it was taken at (0 = none)
     bool lanes_checked = false;           // the lanes' streams have been probed for running side by side
     int lane_stream_swaps = 0;            // streams replaced by that probe
     DeviceBuffer<unsigned long long> d_totals;
@@ -457,6 +467,7 @@ int flatten_and_upload(PtContext* c) {
     s.shading_kind = (other || (metal && glass)) ? 0 : (glass ? 3 : (metal ? 4 : (plain ? 2 : 1)));
     choose_lds_nodes(c);
     c->lanes_for_frame = 0;  // batches in flight are chosen again at the next frame (choose_lanes)
+    c->level_rays_slots = 0;  // and the rays per level measured on the scene before say nothing about this one
     s.planes_ok = 1;
     for (const HostTree::Node& nd : t.nodes)
         for (int k = 0; k < 6; k++)
@@ -695,7 +706,21 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     const bool small_batch = c->frame_samples <= ((size_t)4 << 20) && c->frame_samples > 0;
     // (a tree in memory: 4, and 2 for a small batch as well -- teapot 512 x 384: 5.8 -> 7.5 Grays/s, its kd-tree 2.8 -> 3.8; at 1024 x 1024
     // 11.0 -> 11.7; the 210 k-triangle courtyard +1.4 %; the deep levels of an open scene are nearly empty launches otherwise)
-    const int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : (small_batch ? 2 : 6)) : (small_batch ? 2 : 4)) : c->tail_level;
+    int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : (small_batch ? 2 : 6)) : (small_batch ? 2 : 4)) : c->tail_level;
+    // ... and, once the rays per level of an earlier batch of this size have come back (no wait: the copy is looked at when
+    // its event has passed), from those: the fused launch takes over at the first level that holds fewer than 2.4 M rays
+    // (level 1: fewer than 0.6 M), at level 6 at the latest (4 for a tree in memory).  Measured optima this reproduces: cornellbox 1024 x 1024 6
+    // (level 5 holds 2.45 M), at 512 x 384 2; teapot 2, at 512 x 384 1 (+6 % over 2); bunny 2 (+4 % over 4); the courtyard 4.
+    if (c->level_copy_pending && hipEventQuery(c->level_copied) == hipSuccess) {
+        c->level_copy_pending = false;
+        c->level_rays.assign(c->h_level_rays, c->h_level_rays + c->level_copy_levels);
+        c->level_rays_slots = c->level_copy_slots;
+    }
+    if (c->tail_level == 255 && c->level_rays_slots == b.n_slots && !(in_lds && c->accel == PT_ACCEL_KD && light_shading && !own_stream)) {
+        tail = in_lds ? 6 : 4;  // the latest: where a tree of that kind is handed over with every level well filled
+        for (int level = 1; level < tail && level < (int)c->level_rays.size(); level++)
+            if (c->level_rays[level] < (level == 1 ? 600000ull : 2400000ull)) { tail = level; break; }
+    }
     const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
     const int split = fuse ? tail : levels;
     for (int level = 0; level < split; level++) {
@@ -725,7 +750,15 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     {
         ScopedTimer tm(c, PT_TIMER_ACCUM);
         PT_HIP(c, launch_accumulate(image_cfg, b, ln.d_sample_rad.ptr, c->accum_ptr(), c->d_totals.ptr));
-        PT_HIP(c, launch_tally(image_cfg, ln.d_qcount.ptr, levels, nb, split, b.overflow, c->d_totals.ptr));
+        const bool profile_levels = !c->level_copy_pending && levels <= PtContext::LEVEL_WORDS;
+        PT_HIP(c, launch_tally(image_cfg, ln.d_qcount.ptr, levels, nb, split, b.overflow, c->d_totals.ptr, profile_levels ? c->d_level_rays.ptr : nullptr));
+        if (profile_levels) {  // one copy in flight at a time; looked at when a later batch is queued
+            PT_HIP(c, hipMemcpyAsync(c->h_level_rays, c->d_level_rays.ptr, (size_t)levels * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+            PT_HIP(c, hipEventRecord(c->level_copied, c->stream));
+            c->level_copy_pending = true;
+            c->level_copy_slots = b.n_slots;
+            c->level_copy_levels = levels;
+        }
     }
     if (own_stream) PT_HIP(c, hipEventRecord(ln.consumed[turn], c->stream));
     c->samples_started += (uint64_t)b.n_slots;
@@ -874,6 +907,10 @@ int pt_create(int device, PtContext** out) {
     if (c->d_totals.ensure(DC_COUNT) != hipSuccess || hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)) != hipSuccess ||
         c->d_batch_flags.ensure(FLAG_RING) != hipSuccess || hipMemset(c->d_batch_flags.ptr, 0, FLAG_RING * sizeof(int)) != hipSuccess ||
         c->d_cursors.ensure(TRACE_POOL_INTS) != hipSuccess ||
+        c->d_level_rays.ensure(PtContext::LEVEL_WORDS) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_level_rays, PtContext::LEVEL_WORDS * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_level_rays.ptr, 0xff, PtContext::LEVEL_WORDS * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->level_copied, hipEventDisableTiming) != hipSuccess ||
         c->d_block_stats.ensure((size_t)c->blocks * DC_BLOCK_COUNT) != hipSuccess ||
         hipMemset(c->d_block_stats.ptr, 0, (size_t)c->blocks * DC_BLOCK_COUNT * sizeof(unsigned long long)) != hipSuccess) {
         pt_destroy(c);
@@ -907,7 +944,9 @@ void pt_destroy(PtContext* c) {
         }
         ln.release();
     }
-    c->d_totals.release(); c->d_block_stats.release(); c->d_cursors.release(); c->d_batch_flags.release();
+    c->d_totals.release(); c->d_block_stats.release(); c->d_cursors.release(); c->d_batch_flags.release(); c->d_level_rays.release();
+    if (c->h_level_rays) (void)hipHostFree(c->h_level_rays);
+    if (c->level_copied) (void)hipEventDestroy(c->level_copied);
     c->tb_rays.release(); c->tb_t.release(); c->tb_bary.release(); c->tb_tri.release(); c->tb_o.release(); c->tb_d.release(); c->tb_h.release();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

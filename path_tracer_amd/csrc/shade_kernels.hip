@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void accumulate_kernel(BatchGpu b, const float
 // A batch whose overflow flag is set added nothing to the image and is rendered again in pieces,
 // which are tallied themselves; it is left out here as in accumulate_kernel.
 __global__ __launch_bounds__(256) void tally_kernel(const int* __restrict__ qcount, int blocks, int tail_level,
-                                                    const int* __restrict__ overflow, unsigned long long* __restrict__ totals) {
+                                                    const int* __restrict__ overflow, unsigned long long* __restrict__ totals,
+                                                    unsigned long long* __restrict__ level_rays) {
     __shared__ unsigned long long s_sum[256];
     if (*overflow) return;
     const int level = blockIdx.x;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void tally_kernel(const int* __restrict__ qcou
         if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
         __syncthreads();
     }
+    if (threadIdx.x == 0 && level_rays) level_rays[level] = s_sum[0];  // the batch's population per level, for the host's scheduling
     if (threadIdx.x == 0 && s_sum[0] != 0) {
         atomicAdd(&totals[DC_RAYS], s_sum[0]);
         if (level >= tail_level) atomicAdd(&totals[DC_TAIL_RAYS], s_sum[0]);
@@ -238,8 +240,8 @@ hipError_t launch_accumulate(const LaunchCfg& cfg, const BatchGpu& batch, const 
 }
 
 hipError_t launch_tally(const LaunchCfg& cfg, const int* qcount, int levels, int blocks, int tail_level, const int* overflow,
-                        unsigned long long* totals) {
-    hipLaunchKernelGGL(tally_kernel, dim3(levels), dim3(256), 0, cfg.stream, qcount, blocks, tail_level, overflow, totals);
+                        unsigned long long* totals, unsigned long long* level_rays) {
+    hipLaunchKernelGGL(tally_kernel, dim3(levels), dim3(256), 0, cfg.stream, qcount, blocks, tail_level, overflow, totals, level_rays);
     return hipGetLastError();
 }
 
