@@ -287,6 +287,34 @@ def test_fused_tail_gives_the_per_level_image(gpu_device, obj, accel):
 
 
 @pytest.mark.gpu
+def test_tail_level_follows_the_measured_rays_per_level(gpu_device):
+    """With PT_OPT_TAIL_LEVEL left alone the first batch uses the rule for the scene's kind (level 2 for a
+    frame this small); once that batch's rays per level have been read back, a level that holds few rays
+    hands over earlier (level 1 here), so later frames trace more of their rays in the fused launch --
+    and the image stays the per-level one bit for bit."""
+    def render(tail):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        if tail is not None:
+            s.set_option(pta.OPT_TAIL_LEVEL, tail)
+        s.set_resolution(96, 72)
+        per_frame = []
+        for _ in range(3):
+            before = s.counters()[pta.CNT_TAIL_RAYS]
+            s.pathtrace(16)
+            s.synchronize()
+            per_frame.append(s.counters()[pta.CNT_TAIL_RAYS] - before)
+        return s.accumulation_buffer(), per_frame, s.counters()[pta.CNT_RAYS]
+
+    ref, none, rays_ref = render(0)
+    assert none == [0, 0, 0]
+    img, tail_rays, rays = render(None)
+    assert rays == rays_ref and np.array_equal(img, ref)
+    assert 0 < tail_rays[0] < tail_rays[1] and tail_rays[2] > tail_rays[0]
+    _, fixed, _ = render(1)
+    assert abs(tail_rays[1] - fixed[1]) < 0.1 * fixed[1]  # level 1: every ray after the camera rays' first bounce
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("obj,accel", [("cornellbox.obj", pta.BVH), ("cornellbox.obj", pta.KD), ("teapot.obj", pta.BVH)])
 def test_frames_in_flight_do_not_change_the_image(gpu_device, obj, accel):
     """PT_OPT_STREAMS: consecutive batches run on streams of their own, but the kernels that touch
