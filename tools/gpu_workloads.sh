@@ -4,9 +4,10 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=$1
 cd $R
 : > $O/workloads_$T.jsonl
-for w in cornellbox cornellbox-glass cornellbox-metal cornellbox-alpha cornellball-glass teapot sponza; do
+for w in cornellbox cornellbox-glass cornellbox-metal cornellbox-alpha cornellball-glass teapot teapot-glass testobj bunny sponza; do
   for a in bvh kd; do
-    timeout -k 10 300 python bench.py --workload $w --accel $a --steps 20 --warmup 3 --no-cpu-baseline --no-kd > $O/wl.json 2> $O/wl.err || { tail $O/wl.err; exit 1; }
+    STEPS="--steps 60 --warmup 5"; [ $w = sponza ] && STEPS=""
+    timeout -k 10 300 python bench.py --workload $w --accel $a $STEPS --no-cpu-baseline --no-kd --no-pmc > $O/wl.json 2> $O/wl.err || { tail $O/wl.err; exit 1; }
     tail -1 $O/wl.json >> $O/workloads_$T.jsonl
     python3 -c "
 import json
