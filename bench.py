@@ -593,6 +593,9 @@ def main():
             "fractions": fracs,
             "fp32": {"achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS,
                      "flop_per_ray": FLOP_PER_BOX_TEST * n_box + FLOP_PER_TRI_TEST * n_tri,
+                     # the walk may not fuse a multiply with an add (the reference's bits), so one FLOP per lane and issue
+                     # slot is the most its instruction stream can reach: half the peak above
+                     "frac_of_unfused_peak": tflops / (0.5 * FP32_PEAK_TFLOPS),
                      "definition": "algorithmic: 27 FLOP per slab test + 75 per triangle test, tests counted by the kernel in an untimed pass"},
             "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS if hbm_gbs is not None else None,
                     "definition": "measured HBM bytes per launch / launch time with one frame in flight (the counter passes run that way)"},
