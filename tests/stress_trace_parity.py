@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""GPU stress run, not collected by pytest: closest-hit parity against the CPU oracle on ray batches a hundred
+times the size of the ones in test_gpu_trace_parity.py, every scene, both accelerators, both ray sources of the
+trace kernel (per-workgroup regions and the pooled source of launches that run alone), several seeds.
+usage: stress_trace_parity.py [rays per batch, default 400000] [seeds, default 2]"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import numpy as np  # noqa: E402
+import orc  # noqa: E402
+import path_tracer_amd as pta  # noqa: E402
+from common import load_gpu_scene, ray_batch, scene_path  # noqa: E402
+from test_gpu_trace_parity import check_batch  # noqa: E402
+
+n_rays = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
+seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+SCENES = ["cornellbox.obj", "cornellbox-glass.obj", "cornellbox-alpha.obj", "cornellball-glass.obj", "cube.obj", "textured.obj",
+          "smallsphere.obj", "teapot.obj", "testObj.obj", "bunny.obj"]
+total = 0
+for obj in SCENES:
+    for accel in (pta.BVH, pta.KD):
+        t0 = time.time()
+        s = load_gpu_scene(obj, accel)
+        o = orc.Oracle()
+        assert o.load_obj(scene_path(obj)) == s.num_triangles()
+        if accel == pta.KD:
+            o.import_kd(s.get_tree())  # held node for node equal to the oracle's own builder by the CPU tests
+        else:
+            o.build(orc.BVH)
+        pos = o.get_tris()[0]
+        hits = 0
+        for seed in range(seeds):
+            rays = ray_batch(pos, n_random=n_rays * 3 // 4, n_vertex=n_rays // 12, seed=100 + seed)
+            for mode in (0, 8):
+                s.set_option(pta.OPT_TRAVERSAL, s.get_option(pta.OPT_TRAVERSAL) & ~8 | mode)
+                hits += check_batch(o, s, rays)
+            total += len(rays)
+        print("%-22s %-3s ok: %d rays x 2 sources, %d hits, %.1f s" % (obj, "kd" if accel == pta.KD else "bvh", seeds * len(rays), hits,
+                                                                      time.time() - t0), flush=True)
+        s.close()
+print("all bit-identical:", total, "rays")
