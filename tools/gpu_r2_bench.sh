@@ -5,8 +5,8 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=$1
 cd $R
 timeout -k 10 500 python bench.py > $O/bench_$T.json 2> $O/bench_$T.err || { tail $O/bench_$T.err; exit 1; }
-timeout -k 10 200 python bench.py --force-collective --steps 10 --no-pmc > $O/bench_coll_$T.json 2> $O/bench_coll_$T.err || { tail $O/bench_coll_$T.err; exit 2; }
-timeout -k 10 200 python bench.py --force-collective --strong --workload cornellbox-alpha --steps 5 --no-pmc > $O/bench_coll_alpha_$T.json 2> $O/bench_coll_alpha_$T.err || { tail $O/bench_coll_alpha_$T.err; exit 3; }
+timeout -k 10 200 python bench.py --force-collective --no-pmc --no-cpu-baseline --no-sponza > $O/bench_coll_$T.json 2> $O/bench_coll_$T.err || { tail $O/bench_coll_$T.err; exit 2; }
+timeout -k 10 200 python bench.py --force-collective --strong --workload cornellbox-alpha --steps 60 --no-pmc > $O/bench_coll_alpha_$T.json 2> $O/bench_coll_alpha_$T.err || { tail $O/bench_coll_alpha_$T.err; exit 3; }
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kd --no-sponza --no-pmc > $O/prof_$T.log 2>&1 || { tail $O/prof_$T.log; exit 4; }
 find $O/prof_$T -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_bench_$T.csv
