@@ -459,9 +459,9 @@ def main():
         reducer = FrameReducer(dist, deltas, master)
         first, count = sample_share(frame_spp, world, rank)
         # Paths that fork (translucent surfaces) can outgrow a batch's ray queues; such a batch adds nothing until
-        # it is rendered again at the next synchronisation.  That must happen before the frame's buffer goes into
-        # the reduce, so these scenes wait for the frame (and lose the overlap of reduce and next frame).
-        forks = any(m.opacity < 1.0 - 5e-5 for m in scene.materials())
+        # it is rendered again at the next synchronisation, when its frame's buffer may long be in a reduce.  So
+        # every wait for the renderer below goes through FrameReducer.settle, which hands the wait a buffer of its
+        # own and reduces that too: no frame waits, no sample is lost.
 
     def step():
         if not collective:
@@ -470,11 +470,16 @@ def main():
             # frame k renders into buffer k % 2 while the reduce of frame k-1 is still in flight
             scene.use_external_accum(reducer.begin_frame().data_ptr())
             scene.pathtrace_split(frame_spp, first, count)
-            if forks:
-                scene.synchronize()
             reducer.reduce(frame_spp)
 
+    def settle():
+        if reducer is not None:
+            reducer.settle(scene)
+        else:
+            scene.synchronize()
+
     def fence():
+        settle()
         if reducer is not None:
             reducer.finish()
         torch.cuda.synchronize()
@@ -486,7 +491,7 @@ def main():
     scene.set_option(pta.OPT_COUNT_TESTS, 1)
     scene.reset_counters()
     step()
-    scene.synchronize()
+    settle()
     c = scene.counters()
     n_box = c[pta.CNT_BOX_TESTS] / max(c[pta.CNT_RAYS], 1)
     n_tri = c[pta.CNT_TRI_TESTS] / max(c[pta.CNT_RAYS], 1)

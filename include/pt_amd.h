@@ -225,7 +225,10 @@ int pt_download(PtContext* ctx, int which, float* dst);
 void* pt_accum_device_ptr(PtContext* ctx);
 /* Render into caller-owned device memory (W*H*3 floats) instead; NULL restores the internal one.
  * Takes effect for the launches issued after the call (no synchronisation), so a caller may
- * alternate between two buffers and reduce one while the next frame renders into the other. */
+ * alternate between two buffers and reduce one while the next frame renders into the other.
+ * A batch whose ray queues overflowed (PT_OPT_QUEUE_FACTOR) is rendered again by the next call that waits, into
+ * the buffer that is current THEN: a caller that reduces buffers without waiting names a cleared buffer of its own
+ * before it calls pt_synchronize and sends that through its collective as well. */
 int pt_use_external_accum(PtContext* ctx, void* device_ptr);
 /* Image::save (src/cs488.h:219-232): clamp to [0,1], truncate to 8 bits, PNG, top row first. */
 int pt_save_png(PtContext* ctx, int which, const char* path);

@@ -72,6 +72,18 @@ class FrameReducer:
         self.total_samples += spp_frame
         self.frame_index += 1
 
+    def settle(self, scene, spp_frame=0):
+        """Waits for `scene` (a path_tracer_amd.Scene rendering into this reducer's buffers) without losing samples:
+        a batch whose ray queues overflowed adds nothing until a wait renders it again, and by then the buffer of its
+        frame may already be in a reduce.  So the wait is given a cleared buffer of its own, whatever it renders again
+        lands there, and that buffer goes through the exchange like a frame (of `spp_frame` new samples per pixel,
+        normally none).  Every rank has to call this at the same point of its frame loop; call it before finish(),
+        frame() or anything else that needs all samples in.  Until then the accumulation is short of the batches
+        that overflowed, nothing else."""
+        scene.use_external_accum(self.begin_frame().data_ptr())
+        scene.synchronize()
+        self.reduce(spp_frame)
+
     def finish(self):
         for slot in range(len(self.deltas)):
             self._retire(slot)

@@ -89,3 +89,46 @@ def test_two_rank_reduce_matches_single_process(tmp_path, n_buffers):
     want /= float(spp_frame * frames)
     assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
     assert got.mean() > 0.01
+
+
+def test_settle_reduces_what_a_wait_renders_again():
+    """FrameReducer.settle hands the renderer's wait a cleared buffer and sends it through the exchange: what the wait
+    adds (batches rendered again after a queue overflow) reaches the accumulation, the frames already reduced are
+    not touched, and the sample count does not move.  A stand-in renderer, one rank, CPU tensors."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from path_tracer_amd.distributed import FrameReducer
+
+    deltas = [torch.zeros(12) for _ in range(2)]
+    master = torch.zeros(12)
+    red = FrameReducer(dist, deltas, master)
+
+    class Renderer:
+        target = None
+        late = 0.0  # what an overflowed batch still owes
+
+        def use_external_accum(self, ptr):
+            self.target = next(d for d in deltas if d.data_ptr() == ptr)
+
+        def render(self, value, overflowed):
+            if overflowed:
+                self.late += value
+            else:
+                self.target += value
+
+        def synchronize(self):
+            self.target += self.late
+            self.late = 0.0
+
+    r = Renderer()
+    for frame, overflowed in enumerate((False, True, False)):
+        r.use_external_accum(red.begin_frame().data_ptr())
+        r.render(float(frame + 1), overflowed)
+        red.reduce(4)
+    red.finish()
+    assert torch.all(master == 4.0) and red.total_samples == 12  # frame 2's batch is still owed
+    red.settle(r)
+    assert torch.all(red.frame() == 6.0 / 12) and red.total_samples == 12
+    red.settle(r)  # nothing owed: a cleared buffer goes through, nothing changes
+    assert torch.all(red.frame() == 6.0 / 12)

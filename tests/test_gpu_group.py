@@ -68,6 +68,58 @@ def test_group_of_one_is_the_single_context_image(gpu_device, obj, accel, env):
 
 
 @pytest.mark.gpu
+def test_frame_reducer_settles_overflowed_batches_into_a_buffer_of_their_own(gpu_device):
+    """The one-process-per-GPU form of the same hazard: frames go into the exchange without a wait, so a batch that
+    overflowed is rendered again only at FrameReducer.settle -- into a cleared buffer that is reduced like a frame.
+    The accumulation is short of those batches before, complete after."""
+    import torch
+    import torch.distributed as dist
+    from path_tracer_amd.distributed import FrameReducer
+
+    def scene(factor):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        mats = s.materials()
+        for m in mats:
+            m.opacity = 0.5
+        s.set_materials(mats)
+        s.pre_calc(pta.BVH)
+        s.set_option(pta.OPT_QUEUE_FACTOR, factor)
+        s.set_option(pta.OPT_MAX_BATCH, 64 * 48 * 8)
+        s.set_resolution(64, 48)
+        return s
+
+    ref = scene(64)
+    for _ in range(2):
+        ref.pathtrace(8)
+    want = ref.accumulation_buffer().reshape(-1)
+    s = scene(2)
+    s.set_stream(torch.cuda.current_stream().cuda_stream)
+    n = 64 * 48 * 3
+    deltas = [torch.zeros(n, dtype=torch.float32, device="cuda") for _ in range(2)]
+    master = torch.zeros(n, dtype=torch.float32, device="cuda")
+    red = FrameReducer(dist, deltas, master)  # no process group: one rank, the collective call is skipped
+    for _ in range(2):
+        s.use_external_accum(red.begin_frame().data_ptr())
+        s.pathtrace_split(8, 0, 8)
+        red.reduce(8)
+    red.finish()
+    torch.cuda.synchronize()
+    short = master.cpu().numpy().copy()
+    red.settle(s)
+    red.finish()
+    torch.cuda.synchronize()
+    c = s.counters()
+    assert c[pta.CNT_REPAIRED] > 0 and c[pta.CNT_SAMPLES] == 64 * 48 * 16
+    got = master.cpu().numpy()
+    assert short.sum() < 0.9 * want.sum()  # whole batches were missing
+    assert np.allclose(got, want, rtol=2e-4, atol=1e-5)
+    assert red.total_samples == 16
+    s.use_external_accum(0)
+    s.close()
+    ref.close()
+
+
+@pytest.mark.gpu
 def test_group_completes_overflowed_batches_before_the_reduce(gpu_device):
     """Translucent surfaces everywhere and 2x queues: batches overflow, add nothing at first and are rendered again
     at a synchronisation.  The group has to do that before the frame's buffer enters the reduce, or samples are lost."""
