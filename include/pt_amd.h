@@ -252,7 +252,9 @@ int pt_encode_gif(const char* path, const uint8_t* rgb8, int n_frames, int width
  * RCCL ncclReduce(float, sum) per frame over xGMI adds those buffers onto members[0], which folds the sum into its
  * accumulation buffer and resolves its frame buffer.  The sampler is keyed by (pixel, global sample index), so the
  * image equals the single-GPU one up to the order of the float additions.  Everything is queued on the members'
- * streams; pt_group_synchronize (or pt_download on members[0]) waits.  While a context is in a group it is driven
+ * streams; pt_group_synchronize (or pt_download on members[0]) waits -- and completes the batches whose ray queues
+ * overflowed (PT_OPT_QUEUE_FACTOR): they are rendered again into cleared per-frame buffers, which go through one more
+ * reduce; until such a wait the root's image is short of them.  While a context is in a group it is driven
  * through the group calls only (plus pt_set_camera, pt_download / pt_save_* on members[0], counters and timers);
  * pt_group_destroy releases the communicators and returns the contexts to stand-alone use. */
 int pt_group_create(int n, PtContext* const* members, PtGroup** out);

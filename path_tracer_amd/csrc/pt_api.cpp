@@ -818,6 +818,17 @@ int settle(PtContext* c) {
     return PT_OK;
 }
 
+// The wait of the exported calls.  A member of a group is not settled by itself: what its overflowed batches owe
+// has to go through the group's reduce (group_settle).
+int group_settle(PtGroup* g);
+int group_error(PtGroup* g, std::string& msg);
+int wait_for(PtContext* c) {
+    if (!c->group) return settle(c);
+    const int rc = group_settle(c->group);
+    if (rc != PT_OK) { std::string msg; group_error(c->group, msg); return fail(c, rc, msg); }
+    return PT_OK;
+}
+
 // Batches in flight, unless the caller chose: three -- except for frames of more than 4 Mi samples of a scene whose
 // tree is walked in LDS and whose paths do not fork, where the third brings nothing (cornellbox at 1024 x 1024 x 10:
 // +0.3 %, its kd-tree -1 %; at the reference's 512 x 384 x 10: +15 %; teapot +14 %, cornellbox-alpha +5 %, a
@@ -971,7 +982,7 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
     PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     if (!c->issued.empty()) {  // batches in flight are completed under the settings they started with
-        int rc = settle(c);
+        int rc = wait_for(c);
         if (rc != PT_OK) return rc;
     }
     switch (option) {
@@ -1275,7 +1286,7 @@ int pt_synchronize(PtContext* c) {
     PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
-    return settle(c);
+    return wait_for(c);
     PT_CATCH(c)
 }
 
@@ -1498,7 +1509,7 @@ int pt_camera_samples(PtContext* c, int sample, float* rays6) {
     if (c->width <= 0) return fail(c, PT_ERR_NOT_READY, "pt_set_resolution has not been called");
     const size_t n_pixels = (size_t)c->width * c->height;
     if (n_pixels > c->max_batch) return fail(c, PT_ERR_INVALID_ARG, "pt_camera_samples: more pixels than PT_OPT_MAX_BATCH");
-    int rc = settle(c);  // the lanes are idle after this
+    int rc = wait_for(c);  // the lanes are idle after this
     if (rc != PT_OK) return rc;
     Lane& ln = c->lanes[0];
     rc = ensure_lane(c, ln, n_pixels);
@@ -1558,7 +1569,7 @@ int pt_reset_counters(PtContext* c) {
     PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
-    int rc0 = settle(c);
+    int rc0 = wait_for(c);
     if (rc0 != PT_OK) return rc0;
     PT_HIP(c, hipMemset(c->d_totals.ptr, 0, DC_COUNT * sizeof(unsigned long long)));
     int rc = clear_block_stats(c);
@@ -1636,6 +1647,55 @@ void sample_share(int spp, int n, int r, int& first, int& count) {
     const int base = spp / n, extra = spp % n;
     first = r * base + (r < extra ? r : extra);
     count = base + (r < extra ? 1 : 0);
+}
+
+// One reduce onto the root, each rank's call on the stream its accumulate kernels ran on; the root folds the sum
+// into its accumulation and resolves its frame.
+int exchange(PtGroup* g) {
+    const int n = (int)g->members.size();
+    PT_GNCCL(g, ncclGroupStart());
+    for (int i = 0; i < n; i++) {
+        const ncclResult_t r = ncclReduce(g->delta[i], g->delta[i], g->n_floats, ncclFloat, ncclSum, 0, g->comms[i], g->members[i]->stream);
+        if (r != ncclSuccess) { (void)ncclGroupEnd(); return gfail(g, PT_ERR_RCCL, std::string("ncclReduce: ") + ncclGetErrorString(r)); }
+    }
+    PT_GNCCL(g, ncclGroupEnd());
+    PtContext* root = g->members[0];
+    PT_GHIP(g, hipSetDevice(root->device));
+    PT_GHIP(g, launch_add(cfg_of(root), root->d_accum.ptr, g->delta[0], g->n_floats));
+    PT_GHIP(g, launch_resolve(cfg_of(root), root->d_accum.ptr, root->d_frame.ptr, root->width * root->height, root->total_samples));
+    return PT_OK;
+}
+
+int group_error(PtGroup* g, std::string& msg) { msg = g->error; return PT_OK; }
+
+// Waits for every member.  A batch whose ray queues overflowed (forking paths) added nothing to its frame's buffer, and
+// that buffer has been reduced since; the wait renders such batches again, so every member's per-frame buffer is cleared
+// first, the repairs land there, and if there were any the buffers go through one more reduce (of no new samples).
+// Frames are never held up for this; until the wait the root's image is short of those batches, nothing else.
+int group_settle(PtGroup* g) {
+    uint64_t before = 0, after = 0;
+    if (g->forks) {
+        for (size_t i = 0; i < g->members.size(); i++) {
+            PtContext* c = g->members[i];
+            before += c->repaired_batches;
+            PT_GHIP(g, hipSetDevice(c->device));
+            PT_GHIP(g, launch_clear(cfg_of(c), g->delta[i], g->n_floats));
+        }
+    }
+    for (PtContext* c : g->members) {
+        const int rc = settle(c);
+        if (rc != PT_OK) return gfail(g, rc, c->error);
+        after += c->repaired_batches;
+    }
+    if (g->forks && after != before) {
+        const int rc = exchange(g);
+        if (rc != PT_OK) return rc;
+        for (PtContext* c : g->members) {
+            PT_GHIP(g, hipSetDevice(c->device));
+            PT_GHIP(g, hipStreamSynchronize(c->stream));
+        }
+    }
+    return PT_OK;
 }
 
 void release_group(PtGroup* g) {
@@ -1741,26 +1801,11 @@ int pt_group_render(PtGroup* g, int spp) {
             int rc = render_range(c, spp, first, count);
             if (rc != PT_OK) return gfail(g, rc, c->error);
         }
-        // A batch whose ray queues overflowed (forking paths) adds nothing until it is rendered again at a synchronisation;
-        // that has to happen before the frame's buffer enters the reduce.  Scenes without translucent surfaces cannot
-        // overflow and stay asynchronous.
-        if (g->forks) {
-            for (PtContext* c : g->members) {
-                int rc = settle(c);
-                if (rc != PT_OK) return gfail(g, rc, c->error);
-            }
+        // one reduce per frame onto the root; no member is waited for (group_settle: what an overflowed batch owes)
+        {
+            const int rc = exchange(g);
+            if (rc != PT_OK) return rc;
         }
-        // one reduce per frame onto the root, each rank's call on the stream its accumulate kernels ran on
-        PT_GNCCL(g, ncclGroupStart());
-        for (int i = 0; i < n; i++) {
-            const ncclResult_t r = ncclReduce(g->delta[i], g->delta[i], g->n_floats, ncclFloat, ncclSum, 0, g->comms[i], g->members[i]->stream);
-            if (r != ncclSuccess) { (void)ncclGroupEnd(); return gfail(g, PT_ERR_RCCL, std::string("ncclReduce: ") + ncclGetErrorString(r)); }
-        }
-        PT_GNCCL(g, ncclGroupEnd());
-        PtContext* root = g->members[0];
-        PT_GHIP(g, hipSetDevice(root->device));
-        PT_GHIP(g, launch_add(cfg_of(root), root->d_accum.ptr, g->delta[0], g->n_floats));
-        PT_GHIP(g, launch_resolve(cfg_of(root), root->d_accum.ptr, root->d_frame.ptr, root->width * root->height, root->total_samples));
         g->frames++;
         return PT_OK;
     } catch (...) {
@@ -1770,11 +1815,11 @@ int pt_group_render(PtGroup* g, int spp) {
 
 int pt_group_synchronize(PtGroup* g) {
     if (!g) return PT_ERR_INVALID_ARG;
-    for (PtContext* c : g->members) {
-        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return gfail(g, PT_ERR_HIP, "pt_group_synchronize: stream wait failed");
-        drain_spans(c);
+    try {
+        return group_settle(g);
+    } catch (...) {
+        return gfail(g, PT_ERR_NO_MEMORY, "pt_group_synchronize: exception");
     }
-    return PT_OK;
 }
 
 int pt_group_size(PtGroup* g) { return g ? (int)g->members.size() : PT_ERR_INVALID_ARG; }

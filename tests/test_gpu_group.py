@@ -120,9 +120,11 @@ def test_frame_reducer_settles_overflowed_batches_into_a_buffer_of_their_own(gpu
 
 
 @pytest.mark.gpu
-def test_group_completes_overflowed_batches_before_the_reduce(gpu_device):
+@pytest.mark.parametrize("wait", ["group", "download"])
+def test_group_completes_overflowed_batches_at_the_next_wait(gpu_device, wait):
     """Translucent surfaces everywhere and 2x queues: batches overflow, add nothing at first and are rendered again
-    at a synchronisation.  The group has to do that before the frame's buffer enters the reduce, or samples are lost."""
+    at a wait -- by then their frame's buffer has been through the reduce, so the wait (pt_group_synchronize, or the
+    root's own pt_download) clears the per-frame buffers, lets the repairs land there and reduces once more."""
     def scene(factor):
         s = load_gpu_scene("cornellbox.obj", pta.BVH)
         mats = s.materials()
@@ -142,10 +144,13 @@ def test_group_completes_overflowed_batches_before_the_reduce(gpu_device):
     group = pta.Group([member])
     for _ in range(2):
         group.pathtrace(8)
-    group.synchronize()
+    if wait == "group":
+        group.synchronize()
+    got = member.accumulation_buffer()
     c = member.counters()
     assert c[pta.CNT_REPAIRED] > 0 and c[pta.CNT_SAMPLES] == 64 * 48 * 16
-    assert np.allclose(member.accumulation_buffer(), ref.accumulation_buffer(), rtol=2e-4, atol=1e-5)
+    assert np.allclose(got, ref.accumulation_buffer(), rtol=2e-4, atol=1e-5)
+    assert member.total_samples() == 16
     group.close()
     member.close()
     ref.close()
