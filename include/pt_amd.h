@@ -266,6 +266,10 @@ int pt_group_render(PtGroup* group, int spp);
 /* FrameBuffer.clear + AccumulationBuffer.clear + totalSamples = 0 on every member (src/cs488.h:2288-2290) */
 int pt_group_reset(PtGroup* group);
 int pt_group_synchronize(PtGroup* group);
+/* pt_wait_frames for a group: returns once at most `keep` of the frames queued by pt_group_render are unfinished on
+ * any member (a frame ends on a member with its share of the reduce, on members[0] with the resolved frame).  Renders
+ * no overflowed batch again; pt_group_synchronize before the pixels are read stays as it is. */
+int pt_group_wait_frames(PtGroup* group, int keep);
 
 /* ---- parity entry: Scene::intersect on a batch of rays (src/cs488.h:1750-1777) ------------- */
 /* rays6: n x (origin xyz, direction xyz) in host memory.  tri: index of the winning triangle in

@@ -40,7 +40,7 @@ EXPORTS = [
     "pt_render_split", "pt_resolve", "pt_total_samples", "pt_synchronize", "pt_download", "pt_accum_device_ptr",
     "pt_use_external_accum", "pt_save_png", "pt_save_pfm", "pt_trace_batch", "pt_camera_rays", "pt_get_counters",
     "pt_reset_counters", "pt_get_timers", "pt_trace_batch_static", "pt_camera_samples", "pt_group_create", "pt_group_destroy", "pt_group_last_error",
-    "pt_group_size", "pt_group_render", "pt_group_reset", "pt_group_synchronize", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
+    "pt_group_size", "pt_group_render", "pt_group_reset", "pt_group_synchronize", "pt_group_wait_frames", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
 ]
 
 
@@ -382,6 +382,10 @@ class Group:
 
     def synchronize(self):
         self._check(self.L.pt_group_synchronize(self.h))
+
+    def wait_frames(self, keep=0):
+        """Returns once at most `keep` queued frames are unfinished on any member (pt_group_wait_frames)."""
+        self._check(self.L.pt_group_wait_frames(self.h, int(keep)))
 
     def close(self):
         if getattr(self, "h", None):

@@ -333,9 +333,12 @@ int main(int argc, const char* argv[]) {
         }
         // Scene::Pathtrace, src/cs488.h:1878-1897: on one GPU, or split by samples over the group with one reduce
         rc = cs.group ? pt_group_render(cs.group, opt.spp) : pt_render(ctx, opt.spp);
-        if (rc == PT_OK) rc = cs.group ? pt_group_synchronize(cs.group) : PT_OK;
         const bool pixels_read = recording || !opt.sequence.empty();
-        if (rc == PT_OK) rc = (cs.group || opt.drain_frames || pixels_read) ? pt_synchronize(ctx) : pt_wait_frames(ctx, 2 * (int)in_flight + 2);  // well behind the frames that run: the wait then rarely sleeps
+        const int keep = 2 * (int)in_flight + 2;  // well behind the frames that run: the wait then rarely sleeps
+        if (rc == PT_OK) {
+            if (opt.drain_frames || pixels_read) rc = cs.group ? pt_group_synchronize(cs.group) : pt_synchronize(ctx);
+            else rc = cs.group ? pt_group_wait_frames(cs.group, keep) : pt_wait_frames(ctx, keep);
+        }
         if (rc != PT_OK) return die(cs, "pt_render", rc);
         std::cout << pt_total_samples(ctx) << std::endl;  // src/cs488.h:1896
         if (recording || !opt.sequence.empty()) {

@@ -1806,6 +1806,11 @@ int pt_group_render(PtGroup* g, int spp) {
             const int rc = exchange(g);
             if (rc != PT_OK) return rc;
         }
+        for (PtContext* c : g->members) {  // the frame ends on a member where its share of the exchange does
+            PT_GHIP(g, hipSetDevice(c->device));
+            const int rc = mark_frame_end(c);
+            if (rc != PT_OK) return gfail(g, rc, c->error);
+        }
         g->frames++;
         return PT_OK;
     } catch (...) {
@@ -1819,6 +1824,23 @@ int pt_group_synchronize(PtGroup* g) {
         return group_settle(g);
     } catch (...) {
         return gfail(g, PT_ERR_NO_MEMORY, "pt_group_synchronize: exception");
+    }
+}
+
+int pt_group_wait_frames(PtGroup* g, int keep) {
+    if (!g || keep < 0) return PT_ERR_INVALID_ARG;
+    try {
+        for (PtContext* c : g->members) {
+            PT_GHIP(g, hipSetDevice(c->device));
+            while ((int)c->frame_ends.size() > keep) {
+                PT_GHIP(g, hipEventSynchronize(c->frame_ends.front()));
+                c->event_pool.push_back(c->frame_ends.front());
+                c->frame_ends.pop_front();
+            }
+        }
+        return PT_OK;
+    } catch (...) {
+        return gfail(g, PT_ERR_NO_MEMORY, "pt_group_wait_frames: exception");
     }
 }
 

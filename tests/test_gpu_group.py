@@ -174,3 +174,29 @@ def test_cli_gpus_option_keeps_the_protocol_and_the_image(gpu_device, tmp_path):
         raw = open(pfm, "rb").read()
         outs.append(np.frombuffer(raw[-96 * 72 * 12:], np.float32))
     assert np.allclose(outs[0], outs[1], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_group_wait_frames(gpu_device):
+    """pt_group_wait_frames(keep) paces a frame loop that reads no pixels; the image is the one a loop that waits
+    for every frame gives."""
+    def render(pace):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        s.set_resolution(96, 72)
+        g = pta.Group([s])
+        for _ in range(7):
+            g.pathtrace(4)
+            if pace == "each":
+                g.synchronize()
+            elif pace == "keep2":
+                g.wait_frames(2)
+        g.wait_frames(0)
+        g.wait_frames(3)  # nothing left to wait for
+        with pytest.raises(Exception):
+            g.wait_frames(-1)
+        img = s.frame_buffer()
+        g.close()
+        s.close()
+        return img
+    a, b, c = render("each"), render("keep2"), render("none")
+    assert np.array_equal(a, b) and np.array_equal(a, c)
