@@ -439,10 +439,24 @@ def main():
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # RCCL announces itself (version, host, library path) on standard output when a communicator is made; this
+        # program's standard output is one JSON line, so descriptor 1 points at descriptor 2 until the first
+        # collective has run
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     accel = pta.BVH if args.accel == "bvh" else pta.KD
     scene = make_scene(pta, args, local_rank, accel)
