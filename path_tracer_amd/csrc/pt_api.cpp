@@ -622,8 +622,9 @@ void shape_batch(PtContext* c, const Lane& ln, bool own_stream, BatchGpu& b) {
     if (c->resident_per_cu <= 0) c->resident_per_cu = trace_resident_blocks_per_cu(c->scene, c->accel == PT_ACCEL_KD, c->traversal);
     // with another batch in flight beside this one, five regions per CU leave its kernels room (measured: 5 or 6
     // instead of 8 gains 3-5 % on the cornellbox and the teapot, nothing elsewhere); with two others, four do
-    // where the tree is walked in LDS (+0.5-1.5 %; a tree in memory wants its five: -1 % with four)
-    const int beside = !own_stream ? c->resident_per_cu : (c->n_lanes >= 3 && c->scene.lds_nodes >= c->scene.n_nodes ? 4 : 5);
+    // (a tree walked in LDS +0.5-1.5 %; the teapot's kd-tree +6 %, the glass teapot's +8 %, its BVH and the bunny's
+    // +1-2 %, a 210 k-triangle courtyard -0.5 %)
+    const int beside = !own_stream ? c->resident_per_cu : (c->n_lanes >= 3 ? 4 : 5);
     const int per_cu = c->blocks_per_cu > 0 ? c->blocks_per_cu : (beside < c->resident_per_cu ? beside : c->resident_per_cu);
     const int most = c->cus * per_cu;
     nb = nb < 1 ? 1 : (nb > most ? most : nb);
