@@ -15,7 +15,7 @@
 //   --eye/--lookat/--up x y z, --fov deg   camera globals         (src/cs488.h:75,83-85)
 // Headless additions: --frames N (default 10), --out file.png|.pfm (the `I` key's
 // FrameBuffer.save, src/cs488.h:249-253), --seed N, --device N, --stats (ray statistics and
-// Mrays/s on stderr after the last frame), --sequence PREFIX (every frame to PREFIX%04d.png),
+// Mrays/s on stderr after the last frame; --count-tests adds slab and triangle tests per ray, counted by slower kernels), --sequence PREFIX (every frame to PREFIX%04d.png),
 // --obj-polygons (faces with more than three vertices as triangle fans, negative indices; the
 // reference reads three vertices per face, src/cs488.h:1059), --gpus N (the frame's samples are split over
 // GPUs device .. device+N-1 of this node and summed onto the first with one RCCL reduce per frame, in place of the
@@ -52,7 +52,7 @@ struct Options {
     std::vector<std::string> positional;
     int width = 512, height = 384, spp = 10, frames = 10, accel = PT_ACCEL_KD, device = 0, max_level = 15;
     int gpus = 0;  // 0: one context, no group; N >= 1: a group of N contexts (N = 1 still goes through the reduce)
-    bool progressive = true, stats = false, drain_frames = false;
+    bool progressive = true, stats = false, count_tests = false, drain_frames = false;
     bool have_seed = false;
     uint64_t seed = 0;
     float eye[3] = {0.0f, 0.0f, 1.5f}, lookat[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
@@ -123,7 +123,7 @@ void usage() {
     fprintf(stderr,
             "usage: CS488 <scene.obj> [probe.hdr] [--accel kd|bvh] [--spp N] [--width W --height H] [--frames N]\n"
             "             [--out frame.png|frame.pfm] [--no-progressive] [--max-level N] [--eye x y z] [--lookat x y z]\n"
-            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--gpus N] [--stats] [--headless] [--drain-frames]\n"
+            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--gpus N] [--stats] [--count-tests] [--headless] [--drain-frames]\n"
             "             [--script events.txt] [--sequence PREFIX] [--obj-polygons]\n");
 }
 
@@ -134,6 +134,7 @@ bool parse(int argc, const char* argv[], Options& o) {
         if (a.rfind("--", 0) != 0) { o.positional.push_back(a); continue; }
         if (a == "--headless") continue;  // the only mode there is
         else if (a == "--stats") o.stats = true;
+        else if (a == "--count-tests") { o.stats = true; o.count_tests = true; }
         else if (a == "--drain-frames") o.drain_frames = true;
         else if (a == "--no-progressive") o.progressive = false;
         else if (a == "--accel") { if (!need(i, 1)) return false; std::string v = argv[++i]; if (v == "kd") o.accel = PT_ACCEL_KD; else if (v == "bvh") o.accel = PT_ACCEL_BVH; else { usage(); return false; } }
@@ -245,7 +246,7 @@ int main(int argc, const char* argv[]) {
     rc = cs.each([&](PtContext* c) {
         if (opt.have_seed) pt_set_option(c, PT_OPT_SEED, opt.seed);
         pt_set_option(c, PT_OPT_MAX_LEVEL, (uint64_t)opt.max_level);
-        if (opt.stats) pt_set_option(c, PT_OPT_COUNT_TESTS, 1);
+        if (opt.count_tests) pt_set_option(c, PT_OPT_COUNT_TESTS, 1);  // the counting kernels: one launch per level, slower
         return pt_build(c, opt.accel);
     });
     if (rc != PT_OK) return die(cs, "pt_build", rc);
@@ -373,9 +374,9 @@ int main(int argc, const char* argv[]) {
         }
         if (have && total_seconds > 0) {
             const double rays = (double)cnt[PT_CNT_RAYS];
-            fprintf(stderr, "rays %.0f  samples %.0f  rays/sample %.3f  box tests/ray %.2f  tri tests/ray %.2f  dropped NaN samples %llu\n",
-                    rays, (double)cnt[PT_CNT_SAMPLES], rays / (double)cnt[PT_CNT_SAMPLES], cnt[PT_CNT_BOX_TESTS] / rays,
-                    cnt[PT_CNT_TRI_TESTS] / rays, (unsigned long long)cnt[PT_CNT_NAN_SAMPLES]);
+            fprintf(stderr, "rays %.0f  samples %.0f  rays/sample %.3f  dropped NaN samples %llu\n", rays, (double)cnt[PT_CNT_SAMPLES],
+                    rays / (double)cnt[PT_CNT_SAMPLES], (unsigned long long)cnt[PT_CNT_NAN_SAMPLES]);
+            if (opt.count_tests) fprintf(stderr, "box tests/ray %.2f  tri tests/ray %.2f\n", cnt[PT_CNT_BOX_TESTS] / rays, cnt[PT_CNT_TRI_TESTS] / rays);
             fprintf(stderr, "%.2f Mrays/s  %.2f spp/s over %d frames (%.3f s)\n", rays / total_seconds * 1e-6,
                     (double)opt.spp * frames_done / total_seconds, frames_done, total_seconds);
         }

@@ -160,7 +160,9 @@ def test_cli_stdout_protocol(gpu_device, tmp_path):
                 "--no-progressive", "--stats")
     assert r.returncode == 0
     assert 'Loaded "%s".' % scene_path("probe_64.hdr") in r.stdout and "Building BVH..." in r.stdout
-    assert r.stdout.splitlines()[-2] == "2" and "Mrays/s" in r.stderr
+    assert r.stdout.splitlines()[-2] == "2" and "Mrays/s" in r.stderr and "tests/ray" not in r.stderr
+    r = run_cli(obj, "--accel", "bvh", "--frames", "1", "--spp", "2", "--width", "32", "--height", "24", "--count-tests")
+    assert r.returncode == 0 and "Mrays/s" in r.stderr and "box tests/ray" in r.stderr  # the counting kernels, on request
 
 
 def test_cli_frames_overlap_unless_asked_to_drain(gpu_device, tmp_path):
