@@ -13,20 +13,31 @@ sys.path.insert(0, HERE)
 import numpy as np  # noqa: E402
 import orc  # noqa: E402
 import path_tracer_amd as pta  # noqa: E402
-from common import load_gpu_scene, ray_batch, scene_path  # noqa: E402
+from common import ray_batch, scene_path  # noqa: E402
 from test_gpu_trace_parity import check_batch  # noqa: E402
 
 n_rays = int(sys.argv[1]) if len(sys.argv) > 1 else 400000
 seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 SCENES = ["cornellbox.obj", "cornellbox-glass.obj", "cornellbox-alpha.obj", "cornellball-glass.obj", "cube.obj", "textured.obj",
           "smallsphere.obj", "teapot.obj", "testObj.obj", "bunny.obj"]
+# the 210 k-triangle stand-in for sponza.obj (tools/make_sponza.py), written next to this run's temporary files
+import tempfile  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+from make_sponza import build, write  # noqa: E402
+tmp = tempfile.mkdtemp(prefix="pt_stress_")
+standin = os.path.join(tmp, "sponza_standin.obj")
+write(build(seed=7, detail=1.0), standin)
+SCENES.append(standin)
 total = 0
 for obj in SCENES:
     for accel in (pta.BVH, pta.KD):
         t0 = time.time()
-        s = load_gpu_scene(obj, accel)
+        path = obj if os.path.isabs(obj) else scene_path(obj)
+        s = pta.Scene(0)
+        assert s.load(path), obj
+        s.pre_calc(accel)
         o = orc.Oracle()
-        assert o.load_obj(scene_path(obj)) == s.num_triangles()
+        assert o.load_obj(path) == s.num_triangles()
         if accel == pta.KD:
             o.import_kd(s.get_tree())  # held node for node equal to the oracle's own builder by the CPU tests
         else:
@@ -39,7 +50,7 @@ for obj in SCENES:
                 s.set_option(pta.OPT_TRAVERSAL, s.get_option(pta.OPT_TRAVERSAL) & ~8 | mode)
                 hits += check_batch(o, s, rays)
             total += len(rays)
-        print("%-22s %-3s ok: %d rays x 2 sources, %d hits, %.1f s" % (obj, "kd" if accel == pta.KD else "bvh", seeds * len(rays), hits,
+        print("%-22s %-3s ok: %d rays x 2 sources, %d hits, %.1f s" % (os.path.basename(obj), "kd" if accel == pta.KD else "bvh", seeds * len(rays), hits,
                                                                       time.time() - t0), flush=True)
         s.close()
 print("all bit-identical:", total, "rays")
