@@ -219,7 +219,7 @@ def probe_path(args):
     return path
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, budget_ref=10.0, frames_ref=5, budget_core=6.0, frames_core=3, most_samples=12_000_000):
     """The CPU restatement of the reference's multithreaded loop (column strips, one thread per strip), timed on
     this host on a bounded sample of the same workload: once with one thread per core this process may run on, and
     once under the reference's own rule of 3 x hardware_concurrency threads (src/cs488.h:98)."""
@@ -249,7 +249,7 @@ def cpu_baseline(args):
     o.build(orc.BVH if args.accel == "bvh" else orc.KD)
     # bounded sample: the same view and spp on an image shrunk until one frame is <= 12 M samples
     w, h, shrink = args.width, args.height, 1
-    while (w // shrink) * (h // shrink) * args.spp > 12_000_000:
+    while (w // shrink) * (h // shrink) * args.spp > most_samples:
         shrink *= 2
     w, h = w // shrink, h // shrink
 
@@ -270,13 +270,14 @@ def cpu_baseline(args):
     # the reference's own rule first: numThreads = 3 x hardware_concurrency (src/cs488.h:98); a strip narrower than one
     # column holds no pixel (src/cs488.h:1885-1890), so no more threads than columns
     ref_threads = min(3 * hw, w)
-    mrays, frames, dt = timed(ref_threads, 10.0, 5)
-    core_mrays, core_frames, _ = timed(cores, 6.0, 3)
+    mrays, frames, dt = timed(ref_threads, budget_ref, frames_ref)
+    core_mrays, core_frames, _ = timed(cores, budget_core, frames_core) if frames_core > 0 else (None, 0, 0.0)
     return {
+        "s_per_frame": dt / frames * float(args.width * args.height) / float(w * h),
         "value": mrays, "unit": "Mrays/s", "cores": cores, "threads": ref_threads, "kind": "port",
         "spp_per_s": frames * args.spp / dt * (w * h) / float(args.width * args.height),
         "host": {"hardware_concurrency": hw, "cpus_this_process_may_use": usable, "thread_share": share or None},
-        "one_thread_per_core": {"threads": cores, "value": core_mrays, "frames": core_frames},
+        "one_thread_per_core": {"threads": cores, "value": core_mrays, "frames": core_frames} if core_frames else None,
         "note": "threads = 3 x hardware_concurrency as the reference sets numThreads (src/cs488.h:98), over column strips; the oracle gives every "
                 "strip its own PCG32 stream where the reference's threads share one state.  `cores` is the number of CPUs this process may use.",
         "sample": "%d frame(s) of the same view at %dx%d (1/%d of the workload's resolution per axis) x %d spp; spp_per_s is scaled to the "
@@ -353,9 +354,48 @@ def sponza_record(pta, args, device, stream_handle):
                                       "fp32_TFLOPs": tf, "fp32_frac": tf / FP32_PEAK_TFLOPS}}
         cc = committed_counters(sub, 1)
         if cc:
-            rec["counters"] = summarise_counters(cc)
+            rec["committed_counters"] = summarise_counters(cc)
         out[name] = rec
         s.close()
+    if not args.no_cpu_baseline:
+        # CPU leg of the same view (oracle, SAH BVH; its kd builder is the reference's quadratic one and does not finish
+        # on 210 k triangles): a bounded sample, the image shrunk until a frame holds at most 6 M samples
+        sub.accel = "bvh"
+        out["cpu_baseline"] = cpu_baseline(sub, budget_ref=8.0, frames_ref=2, budget_core=0.0, frames_core=0, most_samples=6_000_000)
+        out["bvh"]["gpu_over_cpu"] = out["bvh"]["Mrays/s"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def config1_record(pta, args, device, stream_handle):
+    """The reference's own published case (README.md:63-65: teapot.obj, SAH BVH, 512x384, 10 spp per frame, 0.5 s per
+    frame on the author's machine): seconds per frame of the GPU path and of the CPU oracle on this host.  The teapot
+    has no emitter, so both are lit by the synthetic probe (the reference's probe is not distributed)."""
+    import copy
+    sub = copy.copy(args)
+    sub.workload, sub.obj, sub.hdr, sub.accel = "teapot", None, None, "bvh"
+    sub.width, sub.height, sub.spp = 512, 384, 10
+    sub.lds_nodes = sub.traversal = sub.tail_level = sub.blocks_per_cu = sub.streams = sub.max_batch = None
+    s = make_scene(pta, sub, device, pta.BVH)
+    s.set_stream(stream_handle)
+    for _ in range(20):
+        s.pathtrace(sub.spp)
+    s.synchronize()
+    s.reset_counters()
+    n = 200
+    t0 = time.perf_counter()
+    for _ in range(n):
+        s.pathtrace(sub.spp)
+    s.synchronize()
+    dt = time.perf_counter() - t0
+    rays = s.counters()[pta.CNT_RAYS]
+    s.close()
+    out = {"workload": "teapot.obj + synthetic probe 512x384, 10 spp/frame, SAH BVH (BASELINE config 1)",
+           "reference_published_s_per_frame": 0.5,
+           "gpu": {"s_per_frame": dt / n, "Mrays/s": rays / dt * 1e-6, "spp_per_s": n * sub.spp / dt, "steps": n}}
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(sub, budget_ref=3.0, frames_ref=8, budget_core=2.0, frames_core=4)
+        out["cpu_baseline"] = cpu
+        out["gpu_over_cpu"] = out["gpu"]["Mrays/s"] / cpu["value"]
     return out
 
 
@@ -375,6 +415,90 @@ def summarise_counters(cc):
                 out[k] = c[k]
         out["cache_source"] = cc["cache_source"]
     return out
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` started plainly (no launcher, WORLD_SIZE unset): this process becomes the parent of N
+    copies of itself, one per GPU, with the environment torch.distributed.run would give them (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT).  The parent never opens the GPU, never imports torch
+    and prints nothing: rank 0 writes the one JSON line to the standard output they share.  Returns the exit code
+    (non-zero as soon as one rank fails; the others are then ended by their own pids)."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PT_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    code = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                for q in live:  # one rank down: the collective of the others would wait for ever
+                    q.terminate()
+    return code
+
+
+class stdout_to_stderr:
+    """RCCL and gloo announce themselves on standard output when a communicator is made; this program's standard output
+    is one JSON line, so descriptor 1 points at descriptor 2 while the group is set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def dry_launch(args, world, rank):
+    """--dry-launch: what the launcher half promises, without a GPU: every rank joins a gloo group and reports itself;
+    rank 0 prints how many did."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    seen = torch.zeros(world, dtype=torch.int64)
+    seen[rank] = 1 + int(os.environ.get("LOCAL_RANK", "0"))
+    with stdout_to_stderr():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_reported": int((seen > 0).sum()),
+                          "local_ranks": [int(v) - 1 for v in seen], "gpus_asked": args.gpus,
+                          "self_launched": os.environ.get("PT_BENCH_SELF_LAUNCHED") == "1", "backend": "gloo"}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def reduce_cadence(frame_ms, n_floats, world):
+    """Frames a rank adds into one per-frame buffer before the buffer is reduced (--reduce-every 0 = this rule).
+    A reduce of B bytes onto one rank over xGMI is priced at 0.1 ms + B / 50 GB/s (ring over the 153 GB/s links at about a
+    third of a link's rate, the small-message end of RCCL's curve) and may cost 3 % of the frames it covers."""
+    if world <= 1:
+        return 1
+    reduce_ms = 0.1 + n_floats * 4.0 / 50e6
+    k = int(np.ceil(reduce_ms / (0.03 * max(frame_ms, 1e-3))))
+    return max(1, min(k, 16))
 
 
 def main():
@@ -407,6 +531,11 @@ def main():
                          "external per-frame buffer and the reduce (a one-rank communicator), so that the path N > 1 takes executes")
     ap.add_argument("--no-sponza", action="store_true", help="skip the sponza stand-in sub-record")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes for live HBM traffic")
+    ap.add_argument("--reduce-every", type=int, default=0,
+                    help="N > 1: frames added into one per-frame buffer before it is reduced onto rank 0 (0 = chosen from the "
+                         "measured frame time so that the reduce costs about 3 %%: 1 for frames of tens of ms, several for 2-ms frames)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, let every one report itself over gloo, print the count and exit: no GPU is touched")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo only rehearses the multi-process path on a box with one GPU")
     args = ap.parse_args()
@@ -419,8 +548,16 @@ def main():
     if args.warmup is None:
         args.warmup = 2 if args.workload == "sponza" else 10
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: start the ranks here, before anything touches the GPU (or imports torch)
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_launch:
+        dry_launch(args, world, rank)
+        return
     # counter passes in child processes first, while this process has not touched the GPU yet
     live_traffic = live_hbm_traffic(args, world) if rank == 0 else None
 
@@ -429,23 +566,18 @@ def main():
     import path_tracer_amd as pta
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d with the RCCL backend needs %d GPUs and this node shows %d (--backend gloo rehearses the "
+                         "multi-process path on fewer)" % (world, world, torch.cuda.device_count()))
     local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     collective = world > 1 or args.force_collective
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        # RCCL announces itself (version, host, library path) on standard output when a communicator is made; this
-        # program's standard output is one JSON line, so descriptor 1 points at descriptor 2 until the first
-        # collective has run
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():  # until the first collective has run
             if args.backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             else:
@@ -453,10 +585,6 @@ def main():
             dist.barrier()
             if args.backend == "nccl":
                 torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
 
     accel = pta.BVH if args.accel == "bvh" else pta.KD
     scene = make_scene(pta, args, local_rank, accel)
@@ -470,7 +598,7 @@ def main():
         from path_tracer_amd.distributed import FrameReducer, sample_share
         deltas = [torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda") for _ in range(2)]
         master = torch.zeros(n_pix * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
-        reducer = FrameReducer(dist, deltas, master)
+        reducer = FrameReducer(dist, deltas, master, every=max(args.reduce_every, 1))
         first, count = sample_share(frame_spp, world, rank)
         # Paths that fork (translucent surfaces) can outgrow a batch's ray queues; such a batch adds nothing until
         # it is rendered again at the next synchronisation, when its frame's buffer may long be in a reduce.  So
@@ -512,16 +640,29 @@ def main():
     hit_frac = c[pta.CNT_HITS] / max(c[pta.CNT_RAYS], 1)
     scene.set_option(pta.OPT_COUNT_TESTS, 0)
 
+    fence()
+    w0 = time.perf_counter()
     for _ in range(args.warmup):
         step()
     fence()
+    if reducer is not None and args.reduce_every <= 0 and args.warmup > 0:
+        # frames per reduce from the frame time just seen (the slowest rank's, so that every rank decides alike)
+        t = torch.tensor([(time.perf_counter() - w0) / args.warmup * 1e3], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reducer.every = reduce_cadence(float(t.item()), n_pix * 3, world)
     # per-stage milliseconds from a few untimed frames with events around every kernel, one frame in
     # flight at a time (with more, a kernel's span includes the time it shares the chip) ...
     # (traversal bit 3: the kernel form of the timed region, not the pooled one a lone frame would get)
     streams = scene.get_option(pta.OPT_STREAMS)
     form = scene.get_option(pta.OPT_TRAVERSAL)
+    tail_setting = scene.get_option(pta.OPT_TAIL_LEVEL)
+    tail_used = scene.get_option(pta.OPT_TAIL_LEVEL_USED)  # where the warm-up frames handed over to the fused launch
     scene.set_option(pta.OPT_STREAMS, 1)
     scene.set_option(pta.OPT_TRAVERSAL, form | 8)
+    # one frame at a time the library would hand some scenes over earlier (a small kd-tree after the camera rays): the
+    # stage pass times the launches of the timed region, so it keeps that region's hand-over level
+    scene.set_option(pta.OPT_TAIL_LEVEL, tail_used if tail_used > 0 else tail_setting)
     scene.reset_counters()
     scene.set_option(pta.OPT_PROFILE, 1)
     stage_frames = min(args.steps, 5)
@@ -537,6 +678,7 @@ def main():
     scene.set_option(pta.OPT_PROFILE, 0)
     scene.set_option(pta.OPT_STREAMS, streams)
     scene.set_option(pta.OPT_TRAVERSAL, form)
+    scene.set_option(pta.OPT_TAIL_LEVEL, tail_setting)
     # ... and the timed region with events around the launches of the dominant kernel only
     scene.reset_counters()
     scene.set_option(pta.OPT_PROFILE, 2)
@@ -558,11 +700,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        r = torch.tensor([rays_local], dtype=torch.float64, device=dev)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_total = float(r.item())
+        per_rank = torch.zeros(world, dtype=torch.float64, device=dev)
+        per_rank[rank] = rays_local
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        rays_total = float(per_rank.sum().item())
+        rays_per_rank = [float(v) for v in per_rank.tolist()]
     else:
         rays_total = rays_local
+        rays_per_rank = [rays_local]
 
     out = None
     if rank == 0:
@@ -618,9 +763,11 @@ def main():
                      "definition": "algorithmic: 27 FLOP per slab test + 75 per triangle test, tests counted by the kernel in an untimed pass"},
             "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS if hbm_gbs is not None else None,
                     "definition": "measured HBM bytes per launch / launch time with one frame in flight (the counter passes run that way)"},
-            "counters": counters,
+            "committed_counters": counters,
             "box_tests_per_ray": n_box, "tri_tests_per_ray": n_tri, "hit_fraction": hit_frac,
             "launches": launches[pta.TIMER_TRACE], "avg_launch_ms": avg_launch_s * 1e3,
+            # sum of the trace launches' durations per frame: above ms_per_step when frames overlap
+            "kernel_ms_per_step": trace_s * 1e3 / args.steps,
             "rays_per_launch": rays_kernel / n_launch,
             "rays_in_fused_tail_fraction": rays_tail / max(rays_local, 1.0),
             # the survey's per-ray byte formula prices node and triangle operands as memory traffic; kept as a named
@@ -642,11 +789,17 @@ def main():
                 "workload": "%s %dx%d, %d spp/frame%s, SAH %s, progressive" % (
                     args.obj or WORKLOADS[args.workload][0] or "sponza stand-in (tools/make_sponza.py)", args.width, args.height,
                     frame_spp if args.strong else args.spp, "" if args.strong else "/GPU", args.accel.upper()),
-                "frames_in_flight": streams, "lane_streams_replaced": int(c[pta.CNT_STREAM_SWAPS]),
+                "frames_in_flight": streams, "fused_tail_from_level": int(tail_used), "lane_streams_replaced": int(c[pta.CNT_STREAM_SWAPS]),
                 "lds_nodes": int(scene.get_option(pta.OPT_LDS_NODES)),
-                "parallelism": ("sample-split x%d + %s reduce of the accumulation buffer" % (
-                    world, "RCCL" if args.backend == "nccl" else "gloo (host-staged rehearsal)")) if collective else "single GPU",
+                "parallelism": ("sample-split x%d + %s reduce of the accumulation buffer every %d frame(s)" % (
+                    world, "RCCL" if args.backend == "nccl" else "gloo (host-staged rehearsal)", reducer.every)) if collective else "single GPU",
+                "reduce_every": reducer.every if reducer is not None else None,
+                "reduces_in_timed_region_and_before": reducer.reduces if reducer is not None else None,
+                "collective_ranks": dist.get_world_size() if collective else None,
+                "collective_backend": dist.get_backend() if collective else None,
+                "self_launched": os.environ.get("PT_BENCH_SELF_LAUNCHED") == "1",
             },
+            "per_rank_Mrays/s": [v / elapsed * 1e-6 for v in rays_per_rank],
             "spp_per_s": frame_spp * args.steps / elapsed,
             "rays_per_sample": rays_total / (float(n_pix) * frame_spp * args.steps),
             "roofline": roof,
@@ -682,6 +835,7 @@ def main():
                 scene.close()
                 scene = None
             out["sponza"] = sponza_record(pta, args, local_rank, stream.cuda_stream)
+            out["config1"] = config1_record(pta, args, local_rank, stream.cuda_stream)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -97,6 +97,9 @@ enum {
     PT_OPT_TREE_IN_LDS = 14,  /* read only: 1 when the built scene's whole tree and its intersection records are staged in LDS by
                                  the trace kernels (small scenes: the walk then has no global-memory path, so instruction
                                  issue and not memory bandwidth bounds it) */
+    PT_OPT_TAIL_LEVEL_USED = 15, /* read only: the level at which the fused launch took over in the batch queued last (0 = every
+                                 level had launches of its own); a measurement that changes the schedule (PT_OPT_STREAMS = 1)
+                                 sets PT_OPT_TAIL_LEVEL to this to keep timing the same launches */
     PT_OPT_STREAMS = 13       /* batches in flight, 1..4.  Unless set, chosen when a frame is queued: 3, or 2 for frames of
                                  more than 4 Mi samples of a scene whose tree is walked in LDS and has no translucent surface
                                  (a third batch gains nothing there); and 2 from the moment the context joins a group or is
@@ -219,6 +222,10 @@ int pt_synchronize(PtContext* ctx);
  * GPU every frame as Scene::Pathtrace's join does (src/cs488.h:1893-1895).  Unlike pt_synchronize it does not render
  * overflowed batches again; pt_synchronize / pt_download before the pixels are read stay as they are. */
 int pt_wait_frames(PtContext* ctx, int keep);
+/* How many of the frames queued by pt_render / pt_render_split have not ended on the GPU yet; looks at the frames' end
+ * events and never waits.  A frame loop that overlaps frames prints a frame's lines (src/cs488.h:1896, 2322: after the
+ * join) once this says the frame is through. */
+int pt_frames_in_flight(PtContext* ctx);
 /* which: 0 = accumulation buffer, 1 = frame buffer.  Synchronises. */
 int pt_download(PtContext* ctx, int which, float* dst);
 /* Device address of the accumulation buffer (W*H*3 floats), for a collective over it. */
@@ -250,7 +257,9 @@ int pt_encode_gif(const char* path, const uint8_t* rgb8, int n_frames, int width
  * holding the same scene, accelerator, camera, options and resolution (the caller sets each of them up alike);
  * member r renders sample indices sample_share(spp, n, r) of every pixel into a per-frame buffer on its GPU, and ONE
  * RCCL ncclReduce(float, sum) per frame over xGMI adds those buffers onto members[0], which folds the sum into its
- * accumulation buffer and resolves its frame buffer.  The sampler is keyed by (pixel, global sample index), so the
+ * accumulation buffer and resolves its frame buffer.  Each member's launches are queued by a host thread of its own; a
+ * member has two per-frame buffers used in turn and its share of the reduce runs on a stream of its own, so the next
+ * frame's accumulate kernels do not queue behind the reduce.  The sampler is keyed by (pixel, global sample index), so the
  * image equals the single-GPU one up to the order of the float additions.  Everything is queued on the members'
  * streams; pt_group_synchronize (or pt_download on members[0]) waits -- and completes the batches whose ray queues
  * overflowed (PT_OPT_QUEUE_FACTOR): they are rendered again into cleared per-frame buffers, which go through one more
@@ -270,6 +279,18 @@ int pt_group_synchronize(PtGroup* group);
  * any member (a frame ends on a member with its share of the reduce, on members[0] with the resolved frame).  Renders
  * no overflowed batch again; pt_group_synchronize before the pixels are read stays as it is. */
 int pt_group_wait_frames(PtGroup* group, int keep);
+/* Frames added into one per-frame buffer before the buffer is reduced (default 1: the reference joins its strips every
+ * frame, src/cs488.h:1893-1895).  A reduce moves W*H*12 bytes per member whatever the frame's sample count, so for frames
+ * of a few milliseconds (12.6 MB against a 2-ms frame at 1024 x 1024 x 10 spp) it is paid once per k frames instead: the
+ * members keep adding frames into their current buffer, every k-th pt_group_render (and every pt_group_synchronize, for
+ * the frames since) reduces it.  The sum is the same; members[0]'s frame buffer then shows the state of the last reduce,
+ * fewer than k frames behind, until pt_group_synchronize / pt_download. */
+int pt_group_set_cadence(PtGroup* group, int frames_per_reduce);
+/* pt_frames_in_flight for a group: the largest count over the members. */
+int pt_group_frames_in_flight(PtGroup* group);
+/* Frames queued and reduces issued since the group was made, and the host threads that queue the members' launches
+ * (one per member, as the reference gives every strip a thread, src/cs488.h:1885-1890; 0 for a group of one). */
+int pt_group_stats(PtGroup* group, uint64_t* frames, uint64_t* reduces, int* host_threads);
 
 /* ---- parity entry: Scene::intersect on a batch of rays (src/cs488.h:1750-1777) ------------- */
 /* rays6: n x (origin xyz, direction xyz) in host memory.  tri: index of the winning triangle in

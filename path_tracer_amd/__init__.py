@@ -24,6 +24,7 @@ ERR_NO_MEMORY, ERR_RCCL = -9, -10
 
 OPT_SEED, OPT_MAX_LEVEL, OPT_COUNT_TESTS, OPT_PROFILE, OPT_MAX_BATCH, OPT_QUEUE_FACTOR, OPT_LDS_NODES, OPT_TRAVERSAL, OPT_TAIL_LEVEL, OPT_BUILD_THREADS, OPT_OBJ_EXTENDED, OPT_BLOCKS_PER_CU, OPT_STREAMS, OPT_TREE_IN_LDS = (
     range(1, 15))
+OPT_TAIL_LEVEL_USED = 15
 CNT_RAYS, CNT_BOX_TESTS, CNT_TRI_TESTS, CNT_SAMPLES, CNT_NAN_SAMPLES, CNT_HITS, CNT_MAX_QUEUE, CNT_REPAIRED, CNT_TAIL_RAYS = range(9)
 CNT_WAVE_STEPS, CNT_WAVE_ROUNDS, CNT_STREAM_SWAPS = 9, 10, 11
 CNT_COUNT = 12
@@ -40,7 +41,7 @@ EXPORTS = [
     "pt_render_split", "pt_resolve", "pt_total_samples", "pt_synchronize", "pt_download", "pt_accum_device_ptr",
     "pt_use_external_accum", "pt_save_png", "pt_save_pfm", "pt_trace_batch", "pt_camera_rays", "pt_get_counters",
     "pt_reset_counters", "pt_get_timers", "pt_trace_batch_static", "pt_camera_samples", "pt_group_create", "pt_group_destroy", "pt_group_last_error",
-    "pt_group_size", "pt_group_render", "pt_group_reset", "pt_group_synchronize", "pt_group_wait_frames", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
+    "pt_group_size", "pt_group_render", "pt_group_reset", "pt_group_synchronize", "pt_group_wait_frames", "pt_group_set_cadence", "pt_group_stats", "pt_frames_in_flight", "pt_group_frames_in_flight", "pt_record_begin", "pt_record_frame", "pt_record_end", "pt_encode_gif",
 ]
 
 
@@ -291,6 +292,10 @@ class Scene:
         """Blocks until at most `keep` of the frames queued by pathtrace / pathtrace_split are unfinished."""
         self._check(self.L.pt_wait_frames(self.h, int(keep)))
 
+    def frames_in_flight(self):
+        """Queued frames that have not ended on the GPU yet (pt_frames_in_flight); never waits."""
+        return self._check(self.L.pt_frames_in_flight(self.h))
+
     def use_external_accum(self, device_ptr):
         self._check(self.L.pt_use_external_accum(self.h, C.c_void_p(device_ptr)))
 
@@ -386,6 +391,16 @@ class Group:
     def wait_frames(self, keep=0):
         """Returns once at most `keep` queued frames are unfinished on any member (pt_group_wait_frames)."""
         self._check(self.L.pt_group_wait_frames(self.h, int(keep)))
+
+    def set_cadence(self, frames_per_reduce):
+        """Frames added into one per-frame buffer before it is reduced (pt_group_set_cadence)."""
+        self._check(self.L.pt_group_set_cadence(self.h, int(frames_per_reduce)))
+
+    def stats(self):
+        """(frames queued, reduces issued, host threads queueing the members' launches)."""
+        f, r, t = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(self.L.pt_group_stats(self.h, C.byref(f), C.byref(r), C.byref(t)))
+        return f.value, r.value, t.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -22,7 +22,10 @@
 // reference's column-strip threads, src/cs488.h:1885-1895; the output lines stay the same), --drain-frames (wait for
 // every frame before the next is queued, as the reference's join at src/cs488.h:1893-1895 does; without it a frame
 // whose pixels nobody reads that frame -- no recording, no --sequence -- only waits until the frame a few before it
-// has ended, so consecutive frames overlap on the GPU and the printed seconds are the time between frames).
+// has ended, so consecutive frames overlap on the GPU.  A frame's two lines are still printed only once the frame HAS
+// ended, as the reference prints them after its join (src/cs488.h:1896, 2322): they wait in a short list until the
+// frame's end event has passed, and the seconds are then the time since the previous frame's lines),
+// --reduce-every K (with --gpus: K frames go into one per-frame buffer before it is reduced, for frames of a few ms).
 //
 // Window input is replaced by a script (--script FILE), one event per line, applied where the
 // reference polls events, i.e. before the frame with that index is rendered (src/cs488.h:2283):
@@ -37,6 +40,7 @@
 // changed (src/cs488.h:2266-2293): translations keep accumulating.
 #include <chrono>
 #include <cmath>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,7 +56,8 @@ struct Options {
     std::vector<std::string> positional;
     int width = 512, height = 384, spp = 10, frames = 10, accel = PT_ACCEL_KD, device = 0, max_level = 15;
     int gpus = 0;  // 0: one context, no group; N >= 1: a group of N contexts (N = 1 still goes through the reduce)
-    bool progressive = true, stats = false, count_tests = false, drain_frames = false;
+    int reduce_every = 1;
+    bool progressive = true, stats = false, count_tests = false, drain_frames = false, trace_frames = false;
     bool have_seed = false;
     uint64_t seed = 0;
     float eye[3] = {0.0f, 0.0f, 1.5f}, lookat[3] = {0.0f, 0.0f, 0.0f}, up[3] = {0.0f, 1.0f, 0.0f};
@@ -123,7 +128,7 @@ void usage() {
     fprintf(stderr,
             "usage: CS488 <scene.obj> [probe.hdr] [--accel kd|bvh] [--spp N] [--width W --height H] [--frames N]\n"
             "             [--out frame.png|frame.pfm] [--no-progressive] [--max-level N] [--eye x y z] [--lookat x y z]\n"
-            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--gpus N] [--stats] [--count-tests] [--headless] [--drain-frames]\n"
+            "             [--up x y z] [--fov deg] [--seed N] [--device N] [--gpus N] [--reduce-every K] [--stats] [--count-tests] [--headless] [--drain-frames]\n"
             "             [--script events.txt] [--sequence PREFIX] [--obj-polygons]\n");
 }
 
@@ -136,6 +141,7 @@ bool parse(int argc, const char* argv[], Options& o) {
         else if (a == "--stats") o.stats = true;
         else if (a == "--count-tests") { o.stats = true; o.count_tests = true; }
         else if (a == "--drain-frames") o.drain_frames = true;
+        else if (a == "--trace-frames") o.trace_frames = true;  // stderr: per printed pair, frames queued and frames unfinished then
         else if (a == "--no-progressive") o.progressive = false;
         else if (a == "--accel") { if (!need(i, 1)) return false; std::string v = argv[++i]; if (v == "kd") o.accel = PT_ACCEL_KD; else if (v == "bvh") o.accel = PT_ACCEL_BVH; else { usage(); return false; } }
         else if (a == "--spp") { if (!need(i, 1)) return false; o.spp = atoi(argv[++i]); }
@@ -145,6 +151,7 @@ bool parse(int argc, const char* argv[], Options& o) {
         else if (a == "--max-level") { if (!need(i, 1)) return false; o.max_level = atoi(argv[++i]); }
         else if (a == "--device") { if (!need(i, 1)) return false; o.device = atoi(argv[++i]); }
         else if (a == "--gpus") { if (!need(i, 1)) return false; o.gpus = atoi(argv[++i]); if (o.gpus < 1 || o.gpus > 64) { usage(); return false; } }
+        else if (a == "--reduce-every") { if (!need(i, 1)) return false; o.reduce_every = atoi(argv[++i]); if (o.reduce_every < 1 || o.reduce_every > 1024) { usage(); return false; } }
         else if (a == "--seed") { if (!need(i, 1)) return false; o.seed = strtoull(argv[++i], nullptr, 0); o.have_seed = true; }
         else if (a == "--fov") { if (!need(i, 1)) return false; o.fov = (float)atof(argv[++i]); }
         else if (a == "--out") { if (!need(i, 1)) return false; o.out = argv[++i]; }
@@ -256,6 +263,7 @@ int main(int argc, const char* argv[]) {
     if (opt.gpus > 0) {
         rc = pt_group_create((int)cs.all.size(), cs.all.data(), &cs.group);
         if (rc != PT_OK) return die(cs, "pt_group_create", rc);
+        if (opt.reduce_every > 1 && (rc = pt_group_set_cadence(cs.group, opt.reduce_every)) != PT_OK) return die(cs, "pt_group_set_cadence", rc);
     }
 
     std::vector<Event> events;
@@ -276,10 +284,35 @@ int main(int argc, const char* argv[]) {
     int frames_done = 0;
     uint64_t in_flight = 2;  // frames the context keeps in flight: as many may be queued ahead of the one waited for
     if (!cs.group) (void)pt_get_option(ctx, PT_OPT_STREAMS, &in_flight);
+    // Frames that have been queued and whose two lines are still to be printed, oldest first: the total sample count the
+    // frame reaches.  A frame's lines go out when the frame has ended on the GPU (src/cs488.h:1893-1896 prints after the
+    // join), never before; `last_print` is when the previous frame's lines went out.
+    std::deque<int> unprinted;
+    int frames_queued = 0, pairs_printed = 0;
+    auto last_print = std::chrono::high_resolution_clock::now();
+    auto print_finished = [&](bool all) {
+        const int unfinished = all ? 0 : (cs.group ? pt_group_frames_in_flight(cs.group) : pt_frames_in_flight(ctx));
+        while ((int)unprinted.size() > (unfinished > 0 ? unfinished : 0)) {
+            pairs_printed++;
+            if (opt.trace_frames) fprintf(stderr, "frame-lines %d queued %d unfinished %d\n", pairs_printed, frames_queued, unfinished > 0 ? unfinished : 0);
+            std::cout << unprinted.front() << std::endl;  // src/cs488.h:1896
+            unprinted.pop_front();
+            const auto now = std::chrono::high_resolution_clock::now();
+            const double seconds = std::chrono::duration_cast<std::chrono::duration<double>>(now - last_print).count();
+            last_print = now;
+            total_seconds += seconds;
+            std::cout << seconds << std::endl;  // src/cs488.h:2322
+        }
+    };
     for (int frame = 0; frame < opt.frames && !quit; frame++) {
-        auto t0 = std::chrono::high_resolution_clock::now();
+        if (unprinted.empty()) last_print = std::chrono::high_resolution_clock::now();  // src/cs488.h:2280
         for (const Event& e : events) {
             if (e.frame != frame) continue;
+            if (e.kind == "save" || (e.kind == "key" && (e.arg == "I" || e.arg == "F"))) {
+                // these read pixels and print: the frames before them end first, and their lines go out first
+                if ((rc = cs.group ? pt_group_synchronize(cs.group) : pt_synchronize(ctx)) != PT_OK) return die(cs, "pt_synchronize", rc);
+                print_finished(true);
+            }
             if (e.kind == "key") {
                 const std::string& k = e.arg;
                 if (k == "W") { eye = eye + 0.1f * view; lookat = lookat + 0.1f * view; }        // SCLFACT, src/cs488.h:70
@@ -341,7 +374,9 @@ int main(int argc, const char* argv[]) {
             else rc = cs.group ? pt_group_wait_frames(cs.group, keep) : pt_wait_frames(ctx, keep);
         }
         if (rc != PT_OK) return die(cs, "pt_render", rc);
-        std::cout << pt_total_samples(ctx) << std::endl;  // src/cs488.h:1896
+        unprinted.push_back(pt_total_samples(ctx));
+        frames_queued++;
+        print_finished(opt.drain_frames || pixels_read);
         if (recording || !opt.sequence.empty()) {
             char name[1200];
             if (recording && (rc = pt_record_frame(ctx)) != PT_OK) return die(cs, "saving a recorded frame", rc);
@@ -352,17 +387,11 @@ int main(int argc, const char* argv[]) {
         }
         names.rand();  // src/cs488.h:2317
         frames_done++;
-        auto t1 = std::chrono::high_resolution_clock::now();
-        const double seconds = std::chrono::duration_cast<std::chrono::duration<double>>(t1 - t0).count();
-        total_seconds += seconds;
-        std::cout << seconds << std::endl;  // src/cs488.h:2322
     }
 
-    {  // what is still in flight belongs to the run's time
-        auto t0 = std::chrono::high_resolution_clock::now();
-        if ((rc = pt_synchronize(ctx)) != PT_OK) return die(cs, "pt_synchronize", rc);
-        total_seconds += std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::high_resolution_clock::now() - t0).count();
-    }
+    // what is still in flight belongs to the run's time, and its lines are still to come
+    if ((rc = pt_synchronize(ctx)) != PT_OK) return die(cs, "pt_synchronize", rc);
+    print_finished(true);
     if (!opt.out.empty() && (rc = save_frame(ctx, opt.out)) != PT_OK) return die(cs, "saving the frame", rc);
     if (opt.stats) {
         uint64_t cnt[PT_CNT_COUNT] = {};

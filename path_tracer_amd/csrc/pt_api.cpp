@@ -13,10 +13,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <deque>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/pt_amd.h"
@@ -126,6 +130,7 @@ struct PtContext {
     int obj_extended = 0;   // pt_load_obj also takes polygons and negative indices
     int build_threads = 0;  // host threads of the tree builders, 0 = all
     int tail_level = 255;  // levels from here on run in the fused kernel; 255 = per scene (6 or 8), 0 = never
+    int tail_level_used = 0;  // where the fused kernel took over in the batch queued last (0 = it did not run)
 
     // device scene
     DeviceBuffer<float4> d_nodes, d_isect, d_tri_pos, d_tri_nrm, d_mats;
@@ -724,6 +729,7 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     }
     const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
     const int split = fuse ? tail : levels;
+    c->tail_level_used = fuse ? tail : 0;
     for (int level = 0; level < split; level++) {
         const QueueSet& in = level == 0 ? camera_rays : q[level & 1];
         const QueueSet& out = q[(level + 1) & 1];
@@ -826,7 +832,16 @@ int group_error(PtGroup* g, std::string& msg);
 int wait_for(PtContext* c) {
     if (!c->group) return settle(c);
     const int rc = group_settle(c->group);
+    (void)hipSetDevice(c->device);  // the group's wait went round the members' devices
     if (rc != PT_OK) { std::string msg; group_error(c->group, msg); return fail(c, rc, msg); }
+    return PT_OK;
+}
+
+// The context's stream may be the null stream, which belongs to whichever device is current on the calling thread:
+// every exported entry that waits for or launches on the stream makes the context's device current first (a process
+// with one context per GPU would otherwise wait on, or launch to, another context's GPU).
+int use_device(PtContext* c) {
+    if (c->device != PT_DEVICE_NONE) PT_HIP(c, hipSetDevice(c->device));
     return PT_OK;
 }
 
@@ -970,6 +985,7 @@ int pt_set_stream(PtContext* c, void* hip_stream) {
     if (c && c->group) return fail(c, PT_ERR_NOT_READY, "the context is a member of a group: use the pt_group_* calls (or destroy the group first)");
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     drain_spans(c);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -982,6 +998,10 @@ int pt_set_stream(PtContext* c, void* hip_stream) {
 int pt_set_option(PtContext* c, int option, uint64_t value) {
     PT_TRY
     if (!c) return PT_ERR_INVALID_ARG;
+    {
+        const int rc = use_device(c);
+        if (rc != PT_OK) return rc;
+    }
     if (!c->issued.empty()) {  // batches in flight are completed under the settings they started with
         int rc = wait_for(c);
         if (rc != PT_OK) return rc;
@@ -1046,6 +1066,7 @@ int pt_get_option(PtContext* c, int option, uint64_t* value) {
         case PT_OPT_BUILD_THREADS: *value = (uint64_t)c->build_threads; break;
         case PT_OPT_OBJ_EXTENDED: *value = (uint64_t)c->obj_extended; break;
         case PT_OPT_BLOCKS_PER_CU: *value = (uint64_t)c->blocks_per_cu; break;
+        case PT_OPT_TAIL_LEVEL_USED: *value = (uint64_t)c->tail_level_used; break;
         case PT_OPT_TREE_IN_LDS: *value = c->built && c->device != PT_DEVICE_NONE ? (uint64_t)trace_scene_in_lds(c->scene) : 0; break;
         default: return fail(c, PT_ERR_INVALID_ARG, "unknown option");
     }
@@ -1297,6 +1318,7 @@ int pt_wait_frames(PtContext* c, int keep) {
     PT_TRY
     if (!c || keep < 0) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipSetDevice(c->device));
     while ((int)c->frame_ends.size() > keep) {
         PT_HIP(c, hipEventSynchronize(c->frame_ends.front()));
         c->event_pool.push_back(c->frame_ends.front());
@@ -1304,6 +1326,17 @@ int pt_wait_frames(PtContext* c, int keep) {
     }
     return PT_OK;
     PT_CATCH(c)
+}
+
+// Frames queued by pt_render / pt_render_split whose end the GPU has not reached yet; never waits.
+int pt_frames_in_flight(PtContext* c) {
+    if (!c) return PT_ERR_INVALID_ARG;
+    if (c->device == PT_DEVICE_NONE) return 0;
+    while (!c->frame_ends.empty() && hipEventQuery(c->frame_ends.front()) == hipSuccess) {
+        c->event_pool.push_back(c->frame_ends.front());
+        c->frame_ends.pop_front();
+    }
+    return (int)c->frame_ends.size();
 }
 
 int pt_download(PtContext* c, int which, float* dst) {
@@ -1327,7 +1360,10 @@ void* pt_accum_device_ptr(PtContext* c) { return c ? (void*)c->accum_ptr() : nul
 // context whose number of lanes the caller has not chosen keeps two from then on.
 static int leave_a_queue_for_the_collective(PtContext* c) {
     if (!c->lanes_auto || c->n_lanes <= 2) return PT_OK;
-    if (c->device != PT_DEVICE_NONE) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+    if (c->device != PT_DEVICE_NONE) {
+        PT_HIP(c, hipSetDevice(c->device));
+        PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
+    }
     c->n_lanes = 2;
     c->lanes_checked = false;
     return PT_OK;
@@ -1512,6 +1548,7 @@ int pt_camera_samples(PtContext* c, int sample, float* rays6) {
     if (n_pixels > c->max_batch) return fail(c, PT_ERR_INVALID_ARG, "pt_camera_samples: more pixels than PT_OPT_MAX_BATCH");
     int rc = wait_for(c);  // the lanes are idle after this
     if (rc != PT_OK) return rc;
+    PT_HIP(c, hipSetDevice(c->device));
     Lane& ln = c->lanes[0];
     rc = ensure_lane(c, ln, n_pixels);
     if (rc != PT_OK) return rc;
@@ -1586,6 +1623,7 @@ int pt_reset_counters(PtContext* c) {
 int pt_get_timers(PtContext* c, double ms[PT_TIMER_COUNT], uint64_t launches[PT_TIMER_COUNT]) {
     if (!c) return PT_ERR_INVALID_ARG;
     if (c->device == PT_DEVICE_NONE) return fail(c, PT_ERR_NOT_READY, "context was created without a GPU");
+    PT_HIP(c, hipSetDevice(c->device));
     PT_HIP(c, hipStreamSynchronize(c->stream));
     drain_spans(c);
     for (int i = 0; i < PT_TIMER_COUNT; i++) {
@@ -1599,13 +1637,66 @@ int pt_get_timers(PtContext* c, double ms[PT_TIMER_COUNT], uint64_t launches[PT_
 // ---- several GPUs in one process: sample split and one RCCL reduce per frame ----------------------
 }  // extern "C"
 
+// A host thread that queues one member's launches.  The reference gives every strip of a frame a thread of its own
+// (src/cs488.h:1885-1890); here every GPU of a group gets one, because a frame is a few dozen launches per member and
+// a short frame (0.4 ms at the reference's own resolution) cannot be queued for eight GPUs by one thread in its time.
+// The thread lives as long as the group, keeps its member's device current, and runs one job at a time.
+struct GroupWorker {
+    std::thread thread;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, quit = false;
+    int rc = PT_OK;
+    void run(int device) {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(m);
+        while (true) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            std::function<int()> j = std::move(job);
+            lk.unlock();
+            int r;
+            try { r = j(); } catch (...) { r = PT_ERR_NO_MEMORY; }
+            lk.lock();
+            rc = r;
+            has_job = false;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> j) {
+        std::lock_guard<std::mutex> lk(m);
+        job = std::move(j);
+        has_job = true;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !has_job; });
+        return rc;
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); }
+        if (thread.joinable()) thread.join();
+    }
+};
+
 struct PtGroup {
     std::vector<PtContext*> members;      // members[0] is the root
     std::vector<ncclComm_t> comms;        // one communicator handle per member (ncclCommInitAll)
-    std::vector<float*> delta;            // per member, on its GPU: the samples it added in the current frame
+    // Per member, on its GPU: two per-frame buffers used in turn.  The member's batches accumulate into the current one
+    // on the member's stream; the reduce of a filled buffer runs on the member's exchange stream, so the accumulate
+    // kernels of the next frame (other buffer) do not queue behind it.
+    std::vector<float*> delta[2];
+    std::vector<hipStream_t> xstream;     // per member: the stream its share of the reduce runs on
+    std::vector<hipEvent_t> filled[2];    // per member and buffer: the buffer's last accumulate has been queued (member's stream)
+    std::vector<hipEvent_t> reduced[2];   // per member and buffer: the reduce that read it has been queued (exchange stream)
+    std::vector<GroupWorker*> workers;    // one host thread per member (none for a group of one)
+    int cur = 0;                          // buffer the current frames go into
+    int cadence = 1;                      // frames added into one buffer before it is reduced (pt_group_set_cadence)
+    int in_buffer = 0;                    // frames in the current buffer that have not been reduced yet
     size_t n_floats = 0;
-    bool forks = false;                   // the scene has translucent surfaces: ray queues may overflow
-    uint64_t frames = 0;
+    uint64_t frames = 0, reduces = 0;
     std::string error;
 };
 
@@ -1650,62 +1741,129 @@ void sample_share(int spp, int n, int r, int& first, int& count) {
     count = base + (r < extra ? 1 : 0);
 }
 
-// One reduce onto the root, each rank's call on the stream its accumulate kernels ran on; the root folds the sum
-// into its accumulation and resolves its frame.
+// Runs job(i) for every member, each on its member's thread, and returns the first failure.
+int on_every_member(PtGroup* g, const std::function<int(int)>& job) {
+    const int n = (int)g->members.size();
+    if (g->workers.empty()) {
+        for (int i = 0; i < n; i++) {
+            PT_GHIP(g, hipSetDevice(g->members[i]->device));
+            const int rc = job(i);
+            if (rc != PT_OK) return gfail(g, rc, g->members[i]->error);
+        }
+        return PT_OK;
+    }
+    for (int i = 0; i < n; i++) g->workers[i]->post([&job, i] { return job(i); });
+    int first_rc = PT_OK;
+    for (int i = 0; i < n; i++) {
+        const int rc = g->workers[i]->wait();
+        if (rc != PT_OK && first_rc == PT_OK) first_rc = gfail(g, rc, g->members[i]->error);
+    }
+    return first_rc;
+}
+
+// Points every member at the group's current buffer, cleared, once no reduce reads it any more.
+int open_buffer(PtGroup* g) {
+    const int b = g->cur;
+    return on_every_member(g, [g, b](int i) -> int {
+        PtContext* c = g->members[i];
+        // the buffer's previous turn was reduced on the exchange stream: the clear waits for that on the device
+        PT_HIP(c, hipStreamWaitEvent(c->stream, g->reduced[b][i], 0));
+        PT_HIP(c, launch_clear(cfg_of(c), g->delta[b][i], g->n_floats));
+        c->ext_accum = g->delta[b][i];
+        return PT_OK;
+    });
+}
+
+// One reduce of the current buffers onto the root, each rank's call on its exchange stream behind the event that
+// marks the buffer filled; the root folds the sum into its accumulation and resolves its frame there too.  Afterwards
+// the other buffer is the current one.
 int exchange(PtGroup* g) {
     const int n = (int)g->members.size();
+    const int b = g->cur;
+    for (int i = 0; i < n; i++) {
+        PtContext* c = g->members[i];
+        PT_GHIP(g, hipSetDevice(c->device));
+        PT_GHIP(g, hipEventRecord(g->filled[b][i], c->stream));
+        PT_GHIP(g, hipStreamWaitEvent(g->xstream[i], g->filled[b][i], 0));
+    }
     PT_GNCCL(g, ncclGroupStart());
     for (int i = 0; i < n; i++) {
-        const ncclResult_t r = ncclReduce(g->delta[i], g->delta[i], g->n_floats, ncclFloat, ncclSum, 0, g->comms[i], g->members[i]->stream);
+        const ncclResult_t r = ncclReduce(g->delta[b][i], g->delta[b][i], g->n_floats, ncclFloat, ncclSum, 0, g->comms[i], g->xstream[i]);
         if (r != ncclSuccess) { (void)ncclGroupEnd(); return gfail(g, PT_ERR_RCCL, std::string("ncclReduce: ") + ncclGetErrorString(r)); }
     }
     PT_GNCCL(g, ncclGroupEnd());
     PtContext* root = g->members[0];
     PT_GHIP(g, hipSetDevice(root->device));
-    PT_GHIP(g, launch_add(cfg_of(root), root->d_accum.ptr, g->delta[0], g->n_floats));
-    PT_GHIP(g, launch_resolve(cfg_of(root), root->d_accum.ptr, root->d_frame.ptr, root->width * root->height, root->total_samples));
+    LaunchCfg xcfg = cfg_of(root);
+    xcfg.stream = g->xstream[0];
+    PT_GHIP(g, launch_add(xcfg, root->d_accum.ptr, g->delta[b][0], g->n_floats));
+    PT_GHIP(g, launch_resolve(xcfg, root->d_accum.ptr, root->d_frame.ptr, root->width * root->height, root->total_samples));
+    for (int i = 0; i < n; i++) {
+        PT_GHIP(g, hipSetDevice(g->members[i]->device));
+        PT_GHIP(g, hipEventRecord(g->reduced[b][i], g->xstream[i]));
+    }
+    g->reduces++;
+    g->in_buffer = 0;
+    g->cur = b ^ 1;
     return PT_OK;
 }
 
 int group_error(PtGroup* g, std::string& msg) { msg = g->error; return PT_OK; }
 
-// Waits for every member.  A batch whose ray queues overflowed (forking paths) added nothing to its frame's buffer, and
-// that buffer has been reduced since; the wait renders such batches again, so every member's per-frame buffer is cleared
-// first, the repairs land there, and if there were any the buffers go through one more reduce (of no new samples).
-// Frames are never held up for this; until the wait the root's image is short of those batches, nothing else.
-int group_settle(PtGroup* g) {
-    uint64_t before = 0, after = 0;
-    if (g->forks) {
-        for (size_t i = 0; i < g->members.size(); i++) {
-            PtContext* c = g->members[i];
-            before += c->repaired_batches;
-            PT_GHIP(g, hipSetDevice(c->device));
-            PT_GHIP(g, launch_clear(cfg_of(c), g->delta[i], g->n_floats));
-        }
-    }
-    for (PtContext* c : g->members) {
-        const int rc = settle(c);
-        if (rc != PT_OK) return gfail(g, rc, c->error);
-        after += c->repaired_batches;
-    }
-    if (g->forks && after != before) {
-        const int rc = exchange(g);
-        if (rc != PT_OK) return rc;
-        for (PtContext* c : g->members) {
-            PT_GHIP(g, hipSetDevice(c->device));
-            PT_GHIP(g, hipStreamSynchronize(c->stream));
-        }
+int wait_for_exchanges(PtGroup* g) {
+    for (size_t i = 0; i < g->members.size(); i++) {
+        PT_GHIP(g, hipSetDevice(g->members[i]->device));
+        PT_GHIP(g, hipStreamSynchronize(g->xstream[i]));
     }
     return PT_OK;
 }
 
+// Waits for every member.  A batch whose ray queues overflowed added nothing to its frame's buffer (any scene can have
+// one when the queues are small against the batch: PT_OPT_QUEUE_FACTOR), and that buffer has been reduced since; the
+// wait renders such batches again.  So the frames not reduced yet go through their reduce first, every member is then
+// pointed at the other buffer, cleared, the repairs land there, and if there were any that buffer goes through one
+// more reduce (of no new samples).  Frames are never held up for this; until the wait the root's image is short of
+// those batches, nothing else.
+int group_settle(PtGroup* g) {
+    if (g->in_buffer > 0) {
+        const int rc = exchange(g);
+        if (rc != PT_OK) return rc;
+    }
+    {
+        const int rc = open_buffer(g);
+        if (rc != PT_OK) return rc;
+    }
+    uint64_t before = 0, after = 0;
+    for (PtContext* c : g->members) before += c->repaired_batches;
+    {
+        const int rc = on_every_member(g, [g](int i) { return settle(g->members[i]); });
+        if (rc != PT_OK) return rc;
+    }
+    for (PtContext* c : g->members) after += c->repaired_batches;
+    if (after != before) {
+        const int rc = exchange(g);
+        if (rc != PT_OK) return rc;
+        const int rc2 = open_buffer(g);
+        if (rc2 != PT_OK) return rc2;
+    }
+    return wait_for_exchanges(g);
+}
+
 void release_group(PtGroup* g) {
+    for (GroupWorker* w : g->workers) { w->stop(); delete w; }
+    g->workers.clear();
     for (size_t i = 0; i < g->members.size(); i++) {
         PtContext* c = g->members[i];
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        if (i < g->xstream.size() && g->xstream[i]) (void)hipStreamSynchronize(g->xstream[i]);
         if (i < g->comms.size() && g->comms[i]) (void)ncclCommDestroy(g->comms[i]);
-        if (i < g->delta.size() && g->delta[i]) (void)hipFree(g->delta[i]);
+        for (int b = 0; b < 2; b++) {
+            if (i < g->delta[b].size() && g->delta[b][i]) (void)hipFree(g->delta[b][i]);
+            if (i < g->filled[b].size() && g->filled[b][i]) (void)hipEventDestroy(g->filled[b][i]);
+            if (i < g->reduced[b].size() && g->reduced[b][i]) (void)hipEventDestroy(g->reduced[b][i]);
+        }
+        if (i < g->xstream.size() && g->xstream[i]) (void)hipStreamDestroy(g->xstream[i]);
         c->ext_accum = nullptr;
         c->group = nullptr;
     }
@@ -1734,13 +1892,17 @@ int pt_group_create(int n, PtContext* const* members, PtGroup** out) {
         PtGroup* g = new PtGroup();
         g->n_floats = (size_t)members[0]->width * members[0]->height * 3;
         g->comms.assign((size_t)n, nullptr);
-        g->delta.assign((size_t)n, nullptr);
+        g->xstream.assign((size_t)n, nullptr);
+        for (int b = 0; b < 2; b++) {
+            g->delta[b].assign((size_t)n, nullptr);
+            g->filled[b].assign((size_t)n, nullptr);
+            g->reduced[b].assign((size_t)n, nullptr);
+        }
         std::vector<int> devices;
         for (int i = 0; i < n; i++) {
             g->members.push_back(members[i]);
             devices.push_back(members[i]->device);
             members[i]->group = g;
-            for (const HostMaterial& m : members[i]->mesh.materials) g->forks = g->forks || !(m.opacity >= 1.0f - PT_EPSILON);
         }
         ncclResult_t r;
         {
@@ -1755,13 +1917,27 @@ int pt_group_create(int n, PtContext* const* members, PtGroup** out) {
         }
         for (int i = 0; i < n; i++) {
             PtContext* c = members[i];
-            if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&g->delta[i], g->n_floats * sizeof(float)) != hipSuccess) {
-                fail(members[0], PT_ERR_HIP, "pt_group_create: no memory for a per-frame buffer");
+            bool ok = hipSetDevice(c->device) == hipSuccess && hipStreamCreateWithFlags(&g->xstream[i], hipStreamNonBlocking) == hipSuccess;
+            for (int b = 0; b < 2 && ok; b++)
+                ok = hipMalloc((void**)&g->delta[b][i], g->n_floats * sizeof(float)) == hipSuccess &&
+                     hipEventCreateWithFlags(&g->filled[b][i], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&g->reduced[b][i], hipEventDisableTiming) == hipSuccess &&
+                     hipEventRecord(g->reduced[b][i], g->xstream[i]) == hipSuccess;
+            if (!ok) {
+                fail(members[0], PT_ERR_HIP, "pt_group_create: no stream, events or memory for a member's per-frame buffers");
                 release_group(g);
                 return PT_ERR_HIP;
             }
-            c->ext_accum = g->delta[i];  // from here on the member's batches accumulate into its per-frame buffer
+            c->ext_accum = g->delta[0][i];  // from here on the member's batches accumulate into a per-frame buffer
+            // the member's stream, two batches in flight and the exchange stream: the four hardware queues of a process
             (void)leave_a_queue_for_the_collective(c);
+        }
+        if (n > 1) {
+            for (int i = 0; i < n; i++) {
+                GroupWorker* w = new GroupWorker();
+                g->workers.push_back(w);
+                w->thread = std::thread(&GroupWorker::run, w, members[i]->device);
+            }
         }
         *out = g;
         int rc = pt_group_reset(g);
@@ -1780,39 +1956,82 @@ const char* pt_group_last_error(PtGroup* g) { return g ? g->error.c_str() : "nul
 
 int pt_group_reset(PtGroup* g) {
     if (!g) return PT_ERR_INVALID_ARG;
-    for (size_t i = 0; i < g->members.size(); i++) {
-        PtContext* c = g->members[i];
-        int rc = pt_reset(c);  // per-frame buffer, frame buffer, total samples
-        if (rc != PT_OK) return gfail(g, rc, c->error);
-        if (i == 0) PT_GHIP(g, launch_clear(cfg_of(c), c->d_accum.ptr, g->n_floats));
+    try {
+        // whatever is on its way to the root belongs to the image that is being thrown away, but it must have landed
+        // before the root's accumulation is cleared
+        int rc = wait_for_exchanges(g);
+        if (rc != PT_OK) return rc;
+        g->in_buffer = 0;
+        rc = on_every_member(g, [g](int i) -> int {
+            PtContext* c = g->members[i];
+            const int r = pt_reset(c);  // current per-frame buffer, frame buffer, total samples
+            if (r != PT_OK) return r;
+            if (i == 0) PT_HIP(c, launch_clear(cfg_of(c), c->d_accum.ptr, g->n_floats));
+            return PT_OK;
+        });
+        return rc;
+    } catch (...) {
+        return gfail(g, PT_ERR_NO_MEMORY, "pt_group_reset: exception");
     }
-    return PT_OK;
+}
+
+int pt_group_set_cadence(PtGroup* g, int frames_per_reduce) {
+    if (!g || frames_per_reduce < 1 || frames_per_reduce > 1024) return gfail(g, PT_ERR_INVALID_ARG, "pt_group_set_cadence: between 1 and 1024 frames per reduce");
+    try {
+        if (g->in_buffer >= frames_per_reduce) {
+            const int rc = exchange(g);
+            if (rc != PT_OK) return rc;
+            const int rc2 = open_buffer(g);
+            if (rc2 != PT_OK) return rc2;
+        }
+        g->cadence = frames_per_reduce;
+        return PT_OK;
+    } catch (...) {
+        return gfail(g, PT_ERR_NO_MEMORY, "pt_group_set_cadence: exception");
+    }
 }
 
 int pt_group_render(PtGroup* g, int spp) {
     if (!g || spp <= 0) return gfail(g, PT_ERR_INVALID_ARG, "pt_group_render: bad arguments");
     try {
         const int n = (int)g->members.size();
-        for (int i = 0; i < n; i++) {
+        const int b = g->cur;
+        const bool fresh = g->in_buffer == 0;  // first frame into this buffer: clear it once its last reduce is through
+        // every member's launches are queued by the member's own thread
+        int rc = on_every_member(g, [g, n, b, spp, fresh](int i) -> int {
             PtContext* c = g->members[i];
-            PT_GHIP(g, hipSetDevice(c->device));
-            PT_GHIP(g, launch_clear(cfg_of(c), g->delta[i], g->n_floats));
+            if (fresh) {
+                PT_HIP(c, hipStreamWaitEvent(c->stream, g->reduced[b][i], 0));
+                PT_HIP(c, launch_clear(cfg_of(c), g->delta[b][i], g->n_floats));
+            }
+            c->ext_accum = g->delta[b][i];
             int first, count;
             sample_share(spp, n, i, first, count);
-            int rc = render_range(c, spp, first, count);
-            if (rc != PT_OK) return gfail(g, rc, c->error);
-        }
-        // one reduce per frame onto the root; no member is waited for (group_settle: what an overflowed batch owes)
-        {
-            const int rc = exchange(g);
+            return render_range(c, spp, first, count);
+        });
+        if (rc != PT_OK) return rc;
+        g->in_buffer++;
+        g->frames++;
+        // one reduce per `cadence` frames onto the root; no member is waited for (group_settle: what an overflowed batch owes)
+        const bool reduce_now = g->in_buffer >= g->cadence;
+        if (reduce_now) {
+            rc = exchange(g);
             if (rc != PT_OK) return rc;
         }
-        for (PtContext* c : g->members) {  // the frame ends on a member where its share of the exchange does
+        for (int i = 0; i < n; i++) {
+            // the frame ends on a member where its share of the exchange does (or, between reduces, its accumulate)
+            PtContext* c = g->members[i];
             PT_GHIP(g, hipSetDevice(c->device));
-            const int rc = mark_frame_end(c);
-            if (rc != PT_OK) return gfail(g, rc, c->error);
+            while (c->frame_ends.size() >= 64) {
+                (void)hipEventSynchronize(c->frame_ends.front());
+                c->event_pool.push_back(c->frame_ends.front());
+                c->frame_ends.pop_front();
+            }
+            hipEvent_t e = take_event(c);
+            if (!e) return gfail(g, PT_ERR_HIP, "no event for the end of the frame");
+            PT_GHIP(g, hipEventRecord(e, reduce_now ? g->xstream[i] : c->stream));
+            c->frame_ends.push_back(e);
         }
-        g->frames++;
         return PT_OK;
     } catch (...) {
         return gfail(g, PT_ERR_NO_MEMORY, "pt_group_render: exception");
@@ -1845,6 +2064,25 @@ int pt_group_wait_frames(PtGroup* g, int keep) {
     }
 }
 
+int pt_group_frames_in_flight(PtGroup* g) {
+    if (!g) return PT_ERR_INVALID_ARG;
+    int most = 0;
+    for (PtContext* c : g->members) {
+        (void)hipSetDevice(c->device);
+        const int n = pt_frames_in_flight(c);
+        most = n > most ? n : most;
+    }
+    return most;
+}
+
 int pt_group_size(PtGroup* g) { return g ? (int)g->members.size() : PT_ERR_INVALID_ARG; }
+
+int pt_group_stats(PtGroup* g, uint64_t* frames, uint64_t* reduces, int* host_threads) {
+    if (!g) return PT_ERR_INVALID_ARG;
+    if (frames) *frames = g->frames;
+    if (reduces) *reduces = g->reduces;
+    if (host_threads) *host_threads = (int)g->workers.size();
+    return PT_OK;
+}
 
 }  // extern "C"

@@ -34,7 +34,7 @@ def _render_share(rank, frame, first, count, w, h):
     return acc
 
 
-def _worker(rank, world, port, spp_frame, frames, w, h, out_path, n_buffers):
+def _worker(rank, world, port, spp_frame, frames, w, h, out_path, n_buffers, every=1):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -44,12 +44,14 @@ def _worker(rank, world, port, spp_frame, frames, w, h, out_path, n_buffers):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     deltas = [torch.zeros(h * w * 3, dtype=torch.float32) for _ in range(n_buffers)]
     master = torch.zeros(h * w * 3, dtype=torch.float32) if rank == 0 else None
-    red = FrameReducer(dist, deltas, master)
+    red = FrameReducer(dist, deltas, master, every=every)
     first, count = sample_share(spp_frame, world, rank)
     for f in range(frames):
         buf = red.begin_frame()
         buf += torch.from_numpy(_render_share(rank, f, first, count, w, h).reshape(-1))
         red.reduce(spp_frame)
+    red.finish()
+    assert red.reduces == (frames + every - 1) // every and red.total_samples == spp_frame * frames
     if rank == 0:
         np.save(out_path, red.frame().numpy().reshape(h, w, 3))
     dist.barrier()
@@ -71,14 +73,16 @@ def test_sample_share_partitions():
         sample_share(8, 2, 2)
 
 
-@pytest.mark.parametrize("n_buffers", [1, 2])
-def test_two_rank_reduce_matches_single_process(tmp_path, n_buffers):
+@pytest.mark.parametrize("n_buffers,every", [(1, 1), (2, 1), (2, 2)])
+def test_two_rank_reduce_matches_single_process(tmp_path, n_buffers, every):
     """n_buffers = 2 is the overlapped form bench.py uses (reduce of frame k in flight while frame
-    k+1 is produced); 3 frames so that a buffer is reused while its reduce is pending."""
+    k+1 is produced); 3 frames so that a buffer is reused while its reduce is pending.  every = 2 is the
+    cadence for short frames: two frames go into one buffer before it is reduced, and the odd third
+    frame is reduced by finish()."""
     import torch.multiprocessing as mp
     world, spp_frame, frames, w, h = 2, 3, 3, 32, 24
     out = str(tmp_path / "frame.npy")
-    mp.spawn(_worker, args=(world, _free_port(), spp_frame, frames, w, h, out, n_buffers), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), spp_frame, frames, w, h, out, n_buffers, every), nprocs=world, join=True)
     got = np.load(out)
     sys.path.insert(0, ROOT)
     from path_tracer_amd.distributed import sample_share

@@ -200,3 +200,79 @@ def test_group_wait_frames(gpu_device):
         return img
     a, b, c = render("each"), render("keep2"), render("none")
     assert np.array_equal(a, b) and np.array_equal(a, c)
+
+
+@pytest.mark.gpu
+def test_group_cadence_reduces_every_kth_frame_and_gives_the_same_image(gpu_device):
+    """pt_group_set_cadence(k): k frames are added into one per-frame buffer before it is reduced; the wait reduces the
+    frames since the last one.  Same samples, same sum up to the order of the float additions."""
+    def render(cadence, frames):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        s.set_resolution(96, 72)
+        g = pta.Group([s])
+        if cadence > 1:
+            g.set_cadence(cadence)
+        for _ in range(frames):
+            g.pathtrace(4)
+        g.synchronize()
+        img, acc, total = s.frame_buffer(), s.accumulation_buffer(), s.total_samples()
+        stats = g.stats()
+        g.close()
+        s.close()
+        return img, acc, total, stats
+    a, acc_a, total_a, st_a = render(1, 7)
+    b, acc_b, total_b, st_b = render(3, 7)
+    assert total_a == total_b == 28
+    assert st_a[:2] == (7, 7) and st_b[:2] == (7, 3)  # 3 + 3 frames by the cadence, the seventh by the wait
+    assert st_a[2] == 0                                # a group of one queues its launches on the caller's thread
+    assert np.allclose(a, b, rtol=2e-6, atol=1e-7) and np.allclose(acc_a, acc_b, rtol=2e-6, atol=1e-6)
+    assert a.mean() > 0.01
+    with pytest.raises(pta.PtError):
+        s = load_gpu_scene("cornellbox.obj", pta.BVH)
+        s.set_resolution(32, 24)
+        g = pta.Group([s])
+        try:
+            g.set_cadence(0)
+        finally:
+            g.close()
+            s.close()
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("obj,env,cadence", [("cornellbox.obj", None, 1), ("cornellbox-alpha.obj", "probe_64.hdr", 1), ("cornellbox.obj", None, 2)])
+def test_group_of_two_gpus_gives_the_single_gpu_image(gpu_device, obj, env, cadence):
+    """Two members on two GPUs (runs only where the node shows at least two): every member's launches queued by its own
+    host thread, ncclCommInitAll over both devices, one grouped ncclReduce per frame on the members' exchange streams.
+    The image on members[0] is the single-GPU image up to the order of the float additions, for a scene whose paths fork
+    (exact fixed-point radiance per sample, so the split changes only the order of the per-sample adds) and one whose
+    paths do not."""
+    if _gpus() < 2:
+        pytest.skip("needs two GPUs in one node")
+    W, H, SPP = 160, 120, 6
+    plain = load_gpu_scene(obj, pta.BVH, env=env)
+    plain.set_resolution(W, H)
+    members = [load_gpu_scene(obj, pta.BVH, env=env, device=d) for d in (0, 1)]
+    for m in members:
+        m.set_resolution(W, H)
+    group = pta.Group(members)
+    if cadence > 1:
+        group.set_cadence(cadence)
+    for _ in range(5):
+        plain.pathtrace(SPP)
+        group.pathtrace(SPP)
+    group.synchronize()
+    assert group.stats()[2] == 2
+    assert members[0].total_samples() == plain.total_samples() == 5 * SPP
+    assert np.allclose(members[0].frame_buffer(), plain.frame_buffer(), rtol=1e-5, atol=1e-6)
+    rays = sum(m.counters()[pta.CNT_RAYS] for m in members)
+    assert rays == plain.counters()[pta.CNT_RAYS]          # the same paths, split by sample index
+    assert min(m.counters()[pta.CNT_RAYS] for m in members) > 0.3 * rays
+    group.close()
+    for m in members:
+        m.close()
+    plain.close()

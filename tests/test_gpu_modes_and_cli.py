@@ -172,12 +172,38 @@ def test_cli_frames_overlap_unless_asked_to_drain(gpu_device, tmp_path):
     outs = []
     for extra in ([], ["--drain-frames"]):
         out = str(tmp_path / ("frame%d.pfm" % len(outs)))
-        r = run_cli(obj, "--accel", "bvh", "--frames", "9", "--spp", "3", "--width", "80", "--height", "60", "--out", out, *extra)
+        r = run_cli(obj, "--accel", "bvh", "--frames", "9", "--spp", "3", "--width", "80", "--height", "60", "--out", out, "--trace-frames", *extra)
         assert r.returncode == 0, r.stderr
         body = r.stdout.splitlines()[4:22]
         assert body[0::2] == [str(3 * k) for k in range(1, 10)] and all(float(x) > 0 for x in body[1::2])
         outs.append(open(out, "rb").read())
+        # a frame's two lines are printed after the frame has ended, as the reference prints them after its join
+        # (src/cs488.h:1893-1896, 2322): the pairs printed never outnumber the frames that are through
+        trace = [l.split() for l in r.stderr.splitlines() if l.startswith("frame-lines")]
+        assert len(trace) == 9 and [int(t[1]) for t in trace] == list(range(1, 10))
+        for t in trace:
+            printed, queued, unfinished = int(t[1]), int(t[3]), int(t[5])
+            assert printed <= queued - unfinished
+        if extra:  # the join: every frame's lines right after the frame
+            assert all(int(t[3]) == int(t[1]) and int(t[5]) == 0 for t in trace)
     assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_frames_in_flight_counts_down_without_waiting(gpu_device):
+    s = load_gpu_scene("cornellbox.obj", pta.BVH)
+    s.set_resolution(512, 384)
+    assert s.frames_in_flight() == 0
+    for _ in range(6):
+        s.pathtrace(10)
+    seen = [s.frames_in_flight()]
+    assert 0 <= seen[0] <= 6
+    s.wait_frames(2)
+    seen.append(s.frames_in_flight())
+    assert seen[1] <= 2
+    s.synchronize()
+    assert s.frames_in_flight() == 0
+    s.close()
 
 
 @pytest.mark.gpu

@@ -1,12 +1,12 @@
 """pt_trace_batch_static -- the closest-hit entry that allocates nothing (its staging is a file-scope
-device array) -- against pt_trace_batch on the same rays: hit flag, triangle index and the bits of
-t, beta and gamma equal, on two calls in a row, the second with a smaller input (the array keeps the
-first call's contents)."""
+device array) -- against pt_trace_batch AND against the CPU oracle on the same rays: hit flag, triangle
+index and the bits of t, beta and gamma equal, on two calls in a row, the second with a smaller input
+(the array keeps the first call's contents)."""
 import numpy as np
 import pytest
 
 import path_tracer_amd as pta
-from common import DeviceArray, load_gpu_scene, ray_batch
+from common import DeviceArray, load_gpu_scene, load_oracle_scene, ray_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -35,12 +35,15 @@ def _same(a, b):
 @pytest.mark.parametrize("obj,accel", [("cornellbox.obj", pta.BVH), ("teapot.obj", pta.KD)])
 def test_static_entry_equals_the_allocating_one(obj, accel):
     s = load_gpu_scene(obj, accel)
+    o = load_oracle_scene(obj, accel, textures=False)  # the checker itself, not only the entry point it mirrors
     pos = s.get_mesh()[0]
     big = ray_batch(pos, n_random=40000, n_vertex=2000, seed=11)
     small = ray_batch(pos, n_random=700, n_vertex=40, seed=12)
     assert small.shape[0] < big.shape[0] <= pta.TRACE_STATIC_MAX_RAYS
     for rays in (big, small):  # the second call reuses the array the first one filled
-        _same(_device_call(s, rays), s.intersect(rays))
+        got = _device_call(s, rays)
+        _same(got, s.intersect(rays))
+        _same(got, o.trace(rays))
     # without the optional barycentric output: that array stays untouched
     got = _device_call(s, small, with_bary=False)
     ref = s.intersect(small)
