@@ -78,7 +78,11 @@ enum {
                                  on interior nodes number less than 1/k of those waiting at a leaf; 0, the default:
                                  4 for a scene held entirely in LDS, else 1; 15 = never leave early); bits 8..14: idle
                                  lanes a wave waits for before it fetches new rays (0, the default: 32 for a scene held
-                                 entirely in LDS, else 8) */
+                                 entirely in LDS, else 8); bit 15 (measurement; a BVH that is walked in memory): nodes are
+                                 fetched as 192-byte records that carry both children's node records, so a step that descends
+                                 takes the child's step without another fetch -- one dependent fetch per two levels of
+                                 BVH::traverse (src/cs488.h:1671-1706).  Measured 20-47 % slower than the 64-byte nodes (the
+                                 walk is bound by the bytes it gathers, not by the length of its fetch chain); off by default */
     PT_OPT_TAIL_LEVEL = 9,    /* bounce levels from this one on are finished by one fused launch in which every
                                  workgroup alternates trace and shade on its own queue region (default 255 = per scene: 6,
                                  the level after Russian roulette starts, src/cs488.h:2153, for a tree held in LDS (2 for

@@ -47,6 +47,8 @@ namespace pt {
 
 struct SceneGpu {
     const float4* nodes;
+    const float4* wide;   // BVH kept in memory: per interior node 12 float4 = the node, its left child's node record, its right
+                          // child's (zeros where a child is a leaf); nullptr when not built
     const int* refs;
     const float4* isect;
     const float4* tri_pos;
@@ -139,6 +141,8 @@ hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const Batch
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
                         int* qcount_out);
 int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode);
+// false when not even one workgroup of the trace kernel could be resident with the scene's LDS stage
+bool trace_kernel_fits(const SceneGpu& scene, int kd, int mode);
 // 1 when the trace kernels stage the scene's whole tree and all intersection records in LDS
 int trace_scene_in_lds(const SceneGpu& scene);
 hipError_t launch_tail(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int kd, int mode, int level0, int levels,

@@ -535,10 +535,14 @@ bool load_jpeg_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h,
 bool load_texture_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err) {
     FILE* fp = fopen(path, "rb");
     if (!fp) { err = std::string("cannot read ") + path; return false; }
-    uint8_t sig[2] = {0, 0};
-    const size_t got = fread(sig, 1, 2, fp);
+    uint8_t sig[18] = {0};
+    const size_t got = fread(sig, 1, sizeof(sig), fp);
     fclose(fp);
-    if (got == 2 && sig[0] == 0xFF && sig[1] == 0xD8) return load_jpeg_rgb8(path, rgb, w, h, err);
+    if (got >= 2 && sig[0] == 0xFF && sig[1] == 0xD8) return load_jpeg_rgb8(path, rgb, w, h, err);
+    if (got >= 2 && sig[0] == 'B' && sig[1] == 'M') return load_bmp_rgb8(path, rgb, w, h, err);
+    if (got >= 8 && sig[0] == 0x89 && sig[1] == 'P') return load_png_rgb8(path, rgb, w, h, err);
+    // a TGA file has no signature: it is tried last, on a plausible header
+    if (looks_like_tga(sig, got)) return load_tga_rgb8(path, rgb, w, h, err);
     return load_png_rgb8(path, rgb, w, h, err);
 }
 

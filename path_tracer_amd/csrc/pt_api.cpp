@@ -133,7 +133,7 @@ struct PtContext {
     int tail_level_used = 0;  // where the fused kernel took over in the batch queued last (0 = it did not run)
 
     // device scene
-    DeviceBuffer<float4> d_nodes, d_isect, d_tri_pos, d_tri_nrm, d_mats;
+    DeviceBuffer<float4> d_nodes, d_wide, d_isect, d_tri_pos, d_tri_nrm, d_mats;
     DeviceBuffer<float2> d_tri_uv;
     DeviceBuffer<int> d_refs;
     DeviceBuffer<uint8_t> d_texels;
@@ -446,6 +446,7 @@ int flatten_and_upload(PtContext* c) {
     PT_HIP(c, hipStreamSynchronize(c->stream));  // the staging vectors die with this scope
 
     SceneGpu& s = c->scene;
+    s.wide = nullptr;  // built on demand (ensure_wide_nodes)
     s.nodes = c->d_nodes.ptr; s.refs = c->d_refs.ptr; s.isect = c->d_isect.ptr;
     s.tri_pos = c->d_tri_pos.ptr; s.tri_nrm = c->d_tri_nrm.ptr; s.tri_uv = c->d_tri_uv.ptr;
     s.mats = c->d_mats.ptr; s.texels = c->d_texels.ptr; s.env = c->d_env.ptr;
@@ -477,6 +478,33 @@ int flatten_and_upload(PtContext* c) {
     for (const HostTree::Node& nd : t.nodes)
         for (int k = 0; k < 6; k++)
             if (nd.box[k] != 0.0f && !(std::fabs(nd.box[k]) >= 1e-17f)) s.planes_ok = 0;
+    return PT_OK;
+}
+
+// The 192-byte node records of the wide BVH walk (PT_OPT_TRAVERSAL bit 15; trace_region's WIDE form): per interior
+// node its 64-byte record followed by those of its left and right child (zeros where a child is a leaf).  Built from
+// the uploaded 64-byte nodes the first time the setting asks for them: three times the node bytes, which a scene
+// that never uses the setting does not pay.
+int ensure_wide_nodes(PtContext* c) {
+    SceneGpu& s = c->scene;
+    if (s.wide || !c->built || c->accel != PT_ACCEL_BVH || s.n_nodes <= 256) return PT_OK;
+    const size_t n = (size_t)s.n_nodes;
+    std::vector<float4> nodes(4 * n), wide(12 * n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    PT_HIP(c, hipSetDevice(c->device));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    PT_HIP(c, hipMemcpy(nodes.data(), c->d_nodes.ptr, nodes.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t g = 0; g < n; g++) {
+        int kid[2];
+        memcpy(&kid[0], &nodes[4 * g + 3].x, 4); memcpy(&kid[1], &nodes[4 * g + 3].y, 4);
+        for (int k = 0; k < 4; k++) wide[12 * g + k] = nodes[4 * g + k];
+        for (int side = 0; side < 2; side++)
+            if (kid[side] >= 0)
+                for (int k = 0; k < 4; k++) wide[12 * g + 4 + 4 * side + k] = nodes[4 * (size_t)kid[side] + k];
+    }
+    PT_HIP(c, c->d_wide.upload(wide.data(), wide.size(), c->stream));
+    PT_HIP(c, hipStreamSynchronize(c->stream));
+    s.wide = c->d_wide.ptr;
+    c->resident_per_cu = 0;
     return PT_OK;
 }
 
@@ -961,7 +989,7 @@ void pt_destroy(PtContext* c) {
     drain_spans(c);
     for (hipEvent_t e : c->frame_ends) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    c->d_nodes.release(); c->d_isect.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
+    c->d_nodes.release(); c->d_wide.release(); c->d_isect.release(); c->d_tri_pos.release(); c->d_tri_nrm.release(); c->d_mats.release(); c->d_tri_uv.release();
     c->d_refs.release(); c->d_texels.release(); c->d_env.release(); c->d_accum.release(); c->d_frame.release();
     for (Lane& ln : c->lanes) {
         if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); }
@@ -1023,13 +1051,30 @@ int pt_set_option(PtContext* c, int option, uint64_t value) {
             c->queue_factor = (int)value; c->batch_hint = 0; for (Lane& ln : c->lanes) ln.batch_alloc = 0; break;
         case PT_OPT_LDS_NODES:
             if (value > 2048 && value != 65535) return fail(c, PT_ERR_INVALID_ARG, "at most 2048 nodes fit the LDS stage");
-            c->lds_nodes_opt = value == 65535 ? -1 : (int)value;
-            if (c->built) choose_lds_nodes(c);
+            {
+                const int before = c->lds_nodes_opt;
+                c->lds_nodes_opt = value == 65535 ? -1 : (int)value;
+                if (c->built && c->device != PT_DEVICE_NONE) {
+                    choose_lds_nodes(c);
+                    // a stage that leaves no room for a single workgroup (the staged nodes are 80 bytes apart, beside
+                    // the traversal stacks) would make every trace launch fail: refused here instead
+                    if (!trace_kernel_fits(c->scene, c->accel == PT_ACCEL_KD, c->traversal)) {
+                        c->lds_nodes_opt = before;
+                        choose_lds_nodes(c);
+                        return fail(c, PT_ERR_INVALID_ARG, "that many nodes do not fit the LDS a workgroup of the trace kernel may use");
+                    }
+                }
+            }
             break;
         case PT_OPT_TRAVERSAL:
             // a wave has 64 lanes: a refill threshold above that could never be met and the walk would not end
-            if (value > 0x7fff || ((value >> 8) & 127) > 64) return fail(c, PT_ERR_INVALID_ARG, "traversal bits 8..14 (refill threshold) above 64, or unknown bits");
-            c->traversal = (int)value; c->resident_per_cu = 0; break;
+            if (value > 0xffff || ((value >> 8) & 127) > 64) return fail(c, PT_ERR_INVALID_ARG, "traversal bits 8..14 (refill threshold) above 64, or unknown bits");
+            c->traversal = (int)value; c->resident_per_cu = 0;
+            if ((value & 0x8000) != 0 && c->built && c->device != PT_DEVICE_NONE) {
+                const int rc = ensure_wide_nodes(c);
+                if (rc != PT_OK) return rc;
+            }
+            break;
         case PT_OPT_OBJ_EXTENDED: c->obj_extended = value != 0; break;
         case PT_OPT_BLOCKS_PER_CU:
             if (value > 8) return fail(c, PT_ERR_INVALID_ARG, "at most 8 workgroups per CU");
@@ -1214,6 +1259,7 @@ int pt_build(PtContext* c, int accel) {
     int rc = flatten_and_upload(c);
     if (rc != PT_OK) return rc;
     c->built = true;
+    if ((c->traversal & 0x8000) != 0) return ensure_wide_nodes(c);
     return PT_OK;
     PT_CATCH(c)
 }

@@ -77,7 +77,13 @@ bool load_hdr(const char* path, HostImage& img, std::string& err);
 bool load_png_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
 // jpeg_decode.cpp: sequential and progressive Huffman-coded JPEG, 8-bit grey or YCbCr, to 8-bit RGB.
 bool load_jpeg_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
-// A map_Kd file by its signature: JPEG or PNG (the reference's stbi_load, src/cs488.h:839-846).
+// tga_bmp.cpp: TGA (true colour, grey, colour-mapped; plain or run-length) and BMP (1/4/8-bit palette, 16/24/32-bit,
+// bit masks; not run-length) to 8-bit RGB, alpha dropped.
+bool looks_like_tga(const uint8_t* header, size_t n);
+bool load_tga_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
+bool load_bmp_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
+// A map_Kd file by its signature: JPEG, PNG, BMP or (no signature: by its header) TGA -- the formats among those the
+// reference's stbi_load reads (src/cs488.h:839-846) that scene files use.
 bool load_texture_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
 bool save_png_rgb8(const char* path, const uint8_t* rgb, int w, int h, std::string& err);
 bool save_pfm(const char* path, const float* rgb_bottom_up, int w, int h, std::string& err);

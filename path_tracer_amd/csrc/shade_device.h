@@ -112,9 +112,11 @@ __device__ __forceinline__ void wave_reserve(bool e0, bool e1, int* lds_counter,
 // (src/cs488.h:2038-2044) several paths share a sample and the order of their additions depends on timing, so such a
 // scene (sc.fixed_radiance) sums in 64-bit fixed point instead -- units of 2^-32, exact and therefore independent of
 // the order; the image is then the same bits run after run, as the reference's is with one thread.  A record is two
-// float4 there: three sums and a word of flags for what fixed point cannot hold (bit 0: NaN; bits 1-3 / 4-6: +inf /
-// -inf or beyond +-2^30 in r, g, b), which accumulate_kernel turns back into the float it stands for.
-enum { RAD_NAN = 1, RAD_POS_INF = 2, RAD_NEG_INF = 16 };
+// float4 there: three sums and a word of flags for what fixed point cannot hold (bits 1-3 / 4-6: +inf / -inf or beyond
+// +-2^30 in r, g, b; bits 7-9: NaN in r, g, b), which accumulate_kernel turns back into the float it stands for,
+// component by component as the float path and the reference's recursion would have produced it (the sample is
+// dropped for a NaN in any component either way, src/cs488.h:1841-1858).
+enum { RAD_POS_INF = 2, RAD_NEG_INF = 16, RAD_NAN = 128 };
 __device__ __forceinline__ void add_radiance(const SceneGpu& sc, float4* sample_rad, int slot, vec3 v) {
     if (!sc.fixed_radiance) {
         float* p = reinterpret_cast<float*>(sample_rad + slot);
@@ -132,7 +134,7 @@ __device__ __forceinline__ void add_radiance(const SceneGpu& sc, float4* sample_
             const long long q = __float2ll_rn(c[k] * 4294967296.0f);
             if (q != 0) atomicAdd(p + k, (unsigned long long)q);
         } else {
-            flags |= isnan(c[k]) ? (unsigned int)RAD_NAN : ((c[k] > 0.0f ? (unsigned int)RAD_POS_INF : (unsigned int)RAD_NEG_INF) << k);
+            flags |= (isnan(c[k]) ? (unsigned int)RAD_NAN : (c[k] > 0.0f ? (unsigned int)RAD_POS_INF : (unsigned int)RAD_NEG_INF)) << k;
         }
     }
     if (flags) atomicOr(reinterpret_cast<unsigned int*>(p + 3), flags);
@@ -149,8 +151,8 @@ __device__ __forceinline__ float4 radiance_of_fixed(const float4& lo, const floa
     for (int k = 0; k < 3; k++) {
         const bool pos = (flags & ((unsigned int)RAD_POS_INF << k)) != 0, neg = (flags & ((unsigned int)RAD_NEG_INF << k)) != 0;
         if (pos || neg) out[k] = pos && neg ? NAN : (pos ? INFINITY : -INFINITY);
+        if (flags & ((unsigned int)RAD_NAN << k)) out[k] = NAN;
     }
-    if (flags & RAD_NAN) out[0] = NAN;
     return make_float4(out[0], out[1], out[2], 0.0f);
 }
 

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void tally_kernel(const int* __restrict__ qcou
                                                     const int* __restrict__ overflow, unsigned long long* __restrict__ totals,
                                                     unsigned long long* __restrict__ level_rays) {
     __shared__ unsigned long long s_sum[256];
-    if (*overflow) return;
+    const bool flagged = *overflow != 0;
     const int level = blockIdx.x;
     unsigned long long part = 0;
     for (int k = threadIdx.x; k < blocks; k += blockDim.x) part += (unsigned long long)qcount[(size_t)level * blocks + k];
@@ -163,8 +163,10 @@ __global__ __launch_bounds__(256) void tally_kernel(const int* __restrict__ qcou
         if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && level_rays) level_rays[level] = s_sum[0];  // the batch's population per level, for the host's scheduling
-    if (threadIdx.x == 0 && s_sum[0] != 0) {
+    // the batch's population per level, for the host's scheduling (also for a flagged batch: the host reads these
+    // words whatever became of the batch, and a flagged batch's counts are as good a profile as any)
+    if (threadIdx.x == 0 && level_rays) level_rays[level] = s_sum[0];
+    if (threadIdx.x == 0 && s_sum[0] != 0 && !flagged) {
         atomicAdd(&totals[DC_RAYS], s_sum[0]);
         if (level >= tail_level) atomicAdd(&totals[DC_TAIL_RAYS], s_sum[0]);
         atomicMax(&totals[DC_MAXQ], s_sum[0]);

@@ -388,7 +388,14 @@ __device__ __forceinline__ void stage_tree(const SceneGpu& sc, float4* lds_nodes
 // the workgroup's waves draw from a pool shared with other workgroups (POOL = true: n and region are
 // unused); called by all 256 threads of the workgroup with the tree already staged.  Ends with the
 // workgroup's hit records written and a barrier passed.
-template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS, bool POOL>
+// WIDE (BVH in memory only): a node outside the LDS stage is fetched as a 192-byte record that carries the node
+// and, behind it, the node records of its two children (SceneGpu::wide).  All three parts are requested at once;
+// the lane takes the node's step and, if that step descends into an interior child, the child's step right away
+// from the part already loaded -- one dependent fetch per two levels of BVH::traverse (src/cs488.h:1671-1706)
+// instead of one per level.  The steps, their order and their stack traffic are the binary walk's own.
+// (Measured slower than the 64-byte nodes on every scene, by 20-47 %: the walk is bound by the bytes it gathers
+// through the vector cache, not by the length of its chain of dependent fetches.  Kept as a measurement setting.)
+template <bool KD, bool COUNT, int SLAB, bool DYNAMIC, bool ALL_LDS, bool POOL, bool WIDE = false>
 __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* __restrict__ ray_o,
                                              const float4* __restrict__ ray_d, float4* __restrict__ hit, int n, size_t region,
                                              unsigned long long* __restrict__ block_stats, int leave_k_and_refill, const TraceLds<KD>& lds,
@@ -602,7 +609,7 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
             if (walking == 0) break;
             if (walking * leave_k < __popcll(lane_mask((unsigned int)cur > (unsigned int)RAY_DONE))) break;
             if (COUNT) n_wave_steps += lane == 0 ? 1 : 0;
-            if (cur >= 0) {
+            if (!WIDE && cur >= 0) {
                 float4 q0, q1, q2, q3;
                 if (ALL_LDS || cur < staged) {
                     const float4* np = lds_item(lds_nodes, cur);
@@ -629,6 +636,62 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 sp += st.push ? 1 : 0;
                 pop_or_finish(!st.descend);
                 cur = st.descend ? st.next : cur;
+                leaf_k = 0;
+            }
+            if (WIDE && cur >= 0) {  // the same visit, and the child's from the record that came with it
+                float4 q0, q1, q2, q3;
+                float4 kid[8];       // WIDE: the node records of the two children, loaded with the node
+                bool have_kids = false;
+                if (ALL_LDS || cur < staged) {
+                    const float4* np = lds_item(lds_nodes, cur);
+                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+                } else if (WIDE) {
+                    const float4* np = sc.wide + 12 * (size_t)cur;
+                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) kid[k] = np[4 + k];
+                    have_kids = true;
+                } else {
+                    const float4* np = sc.nodes + 4 * (size_t)cur;
+                    q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+                }
+                // One visit of an interior node: the reference's decisions, the deferred child to the stack, then
+                // either the child to enter or the next deferred one.
+                auto visit = [&](const float4& n0, const float4& n1, const float4& n2, const float4& n3) {
+                    if (COUNT) n_box += 2;
+                    NodeStep st;
+                    if (FAST) node_step_recip<KD>(n0, n1, n2, n3, o, d, inv, best.t, st);
+                    else node_step<false, KD>(n0, n1, n2, n3, o, d, inv, best.t, st);
+                    // the deferred child goes to the row above the top whether or not it is pushed (that row
+                    // is dead until it is), or to the spare row once the lane's LDS rows are full
+                    const int row = min(sp, LDS_STACK);
+                    s_stack[row * 256 + tid] = st.deferred;
+                    if (KD) s_stack_t[row * 256 + tid] = st.deferred_t;
+                    if (__builtin_expect(lane_mask(st.push && sp >= LDS_STACK) != 0ull, 0)) {
+                        if (st.push && sp >= LDS_STACK) {
+                            deep[sp - LDS_STACK] = st.deferred;
+                            if (KD) deep_t[sp - LDS_STACK] = st.deferred_t;
+                        }
+                    }
+                    sp += st.push ? 1 : 0;
+                    pop_or_finish(!st.descend);
+                    cur = st.descend ? st.next : cur;
+                };
+                visit(q0, q1, q2, q3);
+                if (WIDE) {
+                    // the child just entered is an interior node whose record came with its parent's: its visit now
+                    // (a lane that popped instead stands on an older entry of its stack, never on a child of this node)
+                    const int left_ref = __float_as_int(q3.x), right_ref = __float_as_int(q3.y);
+                    const bool second = have_kids && cur >= 0 && (cur == left_ref || cur == right_ref);
+                    if (lane_mask(second) != 0ull) {
+                        if (second) {
+                            const bool is_left = cur == left_ref;
+                            const float4 c0 = is_left ? kid[0] : kid[4], c1 = is_left ? kid[1] : kid[5];
+                            const float4 c2 = is_left ? kid[2] : kid[6], c3 = is_left ? kid[3] : kid[7];
+                            visit(c0, c1, c2, c3);
+                        }
+                    }
+                }
                 leaf_k = 0;
             }
         }

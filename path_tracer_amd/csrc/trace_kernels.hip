@@ -79,6 +79,52 @@ __global__ __launch_bounds__(256, 6) void trace_kernel(SceneGpu sc, const float4
 #endif
 }
 
+// The same kernel for a BVH that is walked in memory with 192-byte node records (trace_region's WIDE form): 48
+// instead of 16 registers of node data per lane, so it is held to five waves per SIMD, which is what the LDS of the
+// stacks and the staged top of the tree admits anyway.
+template <bool POOL>
+__global__ __launch_bounds__(256, 5) void trace_kernel_wide(SceneGpu sc, const float4* __restrict__ ray_o,
+                                                         const float4* __restrict__ ray_d, float4* __restrict__ hit,
+                                                         const int* __restrict__ n_ptr, int n_fixed, int cap_block, int n_regions,
+                                                         int* __restrict__ cursors, unsigned long long* __restrict__ block_stats,
+                                                         int leave_k) {
+    extern __shared__ float4 lds_nodes[];
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[PT_STAT_WORDS];
+    __shared__ __attribute__((aligned(16))) int s_stack[LdsStack<false>::ROWS * 256];
+    __shared__ __attribute__((aligned(16))) float s_stack_t[4];
+    __shared__ int s_count[POOL ? POOL_REGIONS : 1];
+    const int blk = blockIdx.x;
+    RayPool pool;
+    const int group = blk % POOL_GROUPS;
+    const int per_group = (n_regions + POOL_GROUPS - 1) / POOL_GROUPS;
+    pool.cursor = cursors + group * TRACE_POOL_STRIDE;
+    pool.counts = n_ptr;
+    pool.n_fixed = n_fixed;
+    pool.cap_block = cap_block;
+    pool.first = group * per_group;
+    pool.regions = n_regions - pool.first < per_group ? n_regions - pool.first : per_group;
+    int n = 0;
+    if (!POOL) {
+        if (n_ptr) {
+            n = n_ptr[blk];
+            n = n < cap_block ? n : cap_block;
+        } else {
+            const long long rest = (long long)n_fixed - (long long)blk * cap_block;
+            n = rest <= 0 ? 0 : (rest < cap_block ? (int)rest : cap_block);
+        }
+    }
+    if (POOL ? pool.regions <= 0 : n <= 0) return;
+    stage_tree<false>(sc, lds_nodes);
+    TraceLds<false> lds;
+    lds.nodes = lds_nodes; lds.stat = s_stat; lds.stack = s_stack; lds.stack_t = s_stack_t; lds.count = s_count;
+    trace_region<false, false, SLAB_RECIP, true, false, POOL, true>(sc, ray_o, ray_d, hit, n, (size_t)blk * cap_block, block_stats, leave_k, lds, pool);
+}
+
+// Does `mode` (PT_OPT_TRAVERSAL) ask for the 192-byte node records and can this launch use them?
+inline bool wide_applies(const SceneGpu& scene, int mode, bool kd, bool count) {
+    return (mode & 0x8000) != 0 && !kd && !count && (mode & 1) != 0 && (mode & 4) == 0 && scene.wide != nullptr && !fits_lds(scene);
+}
+
 __global__ void pack_rays_kernel(const float* __restrict__ rays6, int n, float4* ray_o, float4* ray_d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -129,7 +175,15 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
     const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 65 : k_bits);  // 65: with at least one lane walking the product exceeds any count of waiting lanes
     const int leave_k = k | (refill << 8);
 #define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats, leave_k
-    if ((mode & 8) != 0 || cap_block > POOL_MAX_REGION) {  // every workgroup traces its own region (always with the dynamic refill)
+    if (wide_applies(scene, mode, KD, COUNT)) {
+        const size_t lds = dynamic_lds_bytes(scene);
+        if ((mode & 8) != 0 || cap_block > POOL_MAX_REGION)
+            hipLaunchKernelGGL((trace_kernel_wide<false>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays,
+                               n_fixed, cap_block, grid_blocks, cursors, block_stats, leave_k);
+        else
+            hipLaunchKernelGGL((trace_kernel_wide<true>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays,
+                               n_fixed, cap_block, grid_blocks, cursors, block_stats, leave_k);
+    } else if ((mode & 8) != 0 || cap_block > POOL_MAX_REGION) {  // every workgroup traces its own region (always with the dynamic refill)
         if (recip) launch_variant<KD, COUNT, SLAB_RECIP, true, false>(PT_ARGS);
         else launch_variant<KD, COUNT, SLAB_DIVIDE, true, false>(PT_ARGS);
     } else if (dynamic) {
@@ -176,9 +230,23 @@ int resident_of(const SceneGpu& scene) {
 // more regions than that the last, partly filled round costs as much as a full one.
 int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode) {
     const bool recip = (mode & 1) != 0;
+    if (wide_applies(scene, mode, kd != 0, false)) {
+        int w = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_wide<true>, 256, dynamic_lds_bytes(scene)) == hipSuccess && w >= 1)
+            return w > 8 ? 8 : w;
+    }
     int n = kd ? (recip ? resident_of<true, SLAB_RECIP>(scene) : resident_of<true, SLAB_DIVIDE>(scene))
                : (recip ? resident_of<false, SLAB_RECIP>(scene) : resident_of<false, SLAB_DIVIDE>(scene));
     return n < 1 ? 8 : (n > 8 ? 8 : n);
+}
+
+bool trace_kernel_fits(const SceneGpu& scene, int kd, int mode) {
+    // static LDS of the kernel (stacks, counters) + the dynamic stage must stay within the 64 KiB a workgroup gets
+    // without an opt-in; the occupancy query says 0 (or fails) beyond it
+    const bool recip = (mode & 1) != 0;
+    const int n = kd ? (recip ? resident_of<true, SLAB_RECIP>(scene) : resident_of<true, SLAB_DIVIDE>(scene))
+                     : (recip ? resident_of<false, SLAB_RECIP>(scene) : resident_of<false, SLAB_DIVIDE>(scene));
+    return n >= 1;
 }
 
 int trace_scene_in_lds(const SceneGpu& scene) { return fits_lds(scene) ? 1 : 0; }

@@ -25,7 +25,7 @@ def test_every_traversal_setting_gives_the_oracle_hits(gpu_device, obj, accel):
     rays = np.concatenate([rays, extra])
     ref = o.trace(rays)
     s = load_gpu_scene(obj, accel)
-    for mode in (0x00, 0x01, 0x04, 0x05, 0x08, 0x09, 0x21, 0x41, 0x49, 0xF1, 0x2041, 0x0841, 0x4040):
+    for mode in (0x00, 0x01, 0x04, 0x05, 0x08, 0x09, 0x21, 0x41, 0x49, 0xF1, 0x2041, 0x0841, 0x8001, 0x8009, 0x8841, 0x4040):
         s.set_option(pta.OPT_TRAVERSAL, mode)
         got = s.intersect(rays)
         assert np.array_equal(got["tri"], ref["tri"]), hex(mode)
@@ -448,3 +448,21 @@ def test_cli_scripted_input(gpu_device, tmp_path):
     # the generator is the reference's PCG32 (src/cs488.h:130-143): the I key at frame 2 comes after two per-frame draws
     _, vals, _ = orc.pcg32(3)
     assert stills[0] == "output%d.png" % int(1000.0 * float(vals[2]))
+
+
+def test_an_lds_stage_that_cannot_launch_is_refused(gpu_device):
+    """PT_OPT_LDS_NODES beyond what a workgroup's LDS holds beside its traversal stacks is refused when it is set (every
+    trace launch would fail otherwise), and the setting in force stays."""
+    o = load_oracle_scene("teapot.obj", pta.BVH, textures=False)
+    rays = ray_batch(o.get_tris()[0], n_random=3000, n_vertex=100, seed=5)
+    ref = o.trace(rays)
+    s = load_gpu_scene("teapot.obj", pta.BVH)
+    s.set_option(pta.OPT_LDS_NODES, 256)
+    assert s.get_option(pta.OPT_LDS_NODES) == 256
+    with pytest.raises(pta.PtError) as e:
+        s.set_option(pta.OPT_LDS_NODES, 2048)
+    assert e.value.code == pta.ERR_INVALID_ARG
+    assert s.get_option(pta.OPT_LDS_NODES) == 256
+    got = s.intersect(rays)
+    assert np.array_equal(got["tri"], ref["tri"]) and np.array_equal(got["t"].view(np.uint32), ref["t"].view(np.uint32))
+    s.close()

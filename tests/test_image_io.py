@@ -115,3 +115,86 @@ def test_interlaced_png_is_refused_and_scene_still_loads(tmp_path, capfd):
     assert "Unable to load texture" in capfd.readouterr().err
     m = s.get_material(0)
     assert m.textured == 1 and m.tex_width == 0
+
+
+@pytest.mark.parametrize("fmt,mode,kw", [
+    ("tga", "RGB", {}), ("tga", "RGBA", {}), ("tga", "L", {}), ("tga", "P", {}),
+    ("tga", "RGB", {"compression": "tga_rle"}), ("tga", "RGBA", {"compression": "tga_rle"}), ("tga", "L", {"compression": "tga_rle"}),
+    ("tga", "P", {"compression": "tga_rle"}),
+    ("bmp", "RGB", {}), ("bmp", "RGBA", {}), ("bmp", "L", {}), ("bmp", "P", {}), ("bmp", "1", {}),
+])
+def test_tga_and_bmp_textures(tmp_path, fmt, mode, kw):
+    """map_Kd files in the two other formats scene files use (the reference's stbi_load reads them, src/cs488.h:839-846):
+    files written by Pillow, read through the .mtl loader, compared with Pillow's own decoding to RGB (alpha dropped).
+    The reference holds no such file, so parity with its decoder is not pinned beyond this."""
+    rng = np.random.default_rng(5)
+    w, h = 37, 21  # odd sizes: BMP rows are padded to four bytes
+    if mode == "P":
+        img = Image.fromarray(rng.integers(0, 256, (h, w), dtype=np.uint8), "P")
+        img.putpalette(list(rng.integers(0, 256, 768, dtype=np.uint8)))
+    elif mode == "1":
+        img = Image.fromarray((rng.integers(0, 2, (h, w), dtype=np.uint8) * 255), "L").convert("1")
+    else:
+        n = {"L": 1, "RGB": 3, "RGBA": 4}[mode]
+        arr = rng.integers(0, 256, (h, w, n), dtype=np.uint8)
+        # runs, so that a run-length encoder has something to encode
+        arr[3:9, 5:30] = arr[3, 5]
+        img = Image.fromarray(arr[..., 0] if n == 1 else arr, mode)
+    name = "tex." + fmt
+    img.save(tmp_path / name, **kw)
+    got = _texture_via_mtl(tmp_path, name)
+    back = Image.open(tmp_path / name)
+    want = np.asarray(back.convert("RGBA").convert("RGB") if back.mode in ("RGBA", "LA") else back.convert("RGB"), np.uint8)
+    if back.mode == "RGBA":  # alpha is dropped, not composited
+        want = np.asarray(back, np.uint8)[..., :3]
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_bottom_up_and_top_down_tga_and_16_bit_pixels(tmp_path):
+    """Hand-written headers for what Pillow does not write: a bottom-up TGA (descriptor bit 5 clear), 16-bit TGA pixels
+    (1-5-5-5, scaled as x * 255 / 31), a top-down 32-bit BMP with bit masks and a 16-bit 5-6-5 BMP."""
+    import struct
+    w, h = 5, 3
+    rng = np.random.default_rng(9)
+    px = rng.integers(0, 1 << 15, (h, w), dtype=np.uint16)
+    for top_down in (False, True):
+        hdr = struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, w, h, 16, 0x20 if top_down else 0)
+        (tmp_path / "t16.tga").write_bytes(hdr + px.astype("<u2").tobytes())
+        got = _texture_via_mtl(tmp_path, "t16.tga")
+        rows = px if top_down else px[::-1]
+        want = np.stack([(((rows >> 10) & 31).astype(np.uint32) * 255) // 31, (((rows >> 5) & 31).astype(np.uint32) * 255) // 31,
+                         ((rows & 31).astype(np.uint32) * 255) // 31], -1).astype(np.uint8)
+        assert np.array_equal(got, want)
+    # 32-bit BMP, top-down (negative height), BI_BITFIELDS with R and B swapped against the default
+    v = rng.integers(0, 1 << 32, (h, w), dtype=np.uint64).astype(np.uint32)
+    masks = (0x000000FF, 0x0000FF00, 0x00FF0000)
+    body = v.astype("<u4").tobytes()
+    head = struct.pack("<2sIHHI", b"BM", 14 + 40 + 12 + len(body), 0, 0, 14 + 40 + 12)
+    dib = struct.pack("<IiiHHIIiiII", 40, w, -h, 1, 32, 3, len(body), 0, 0, 0, 0) + struct.pack("<III", *masks)
+    (tmp_path / "m.bmp").write_bytes(head + dib + body)
+    got = _texture_via_mtl(tmp_path, "m.bmp")
+    want = np.stack([(v >> 0) & 255, (v >> 8) & 255, (v >> 16) & 255], -1).astype(np.uint8)
+    assert np.array_equal(got, want)
+    # 16-bit 5-6-5 BMP, bottom-up, rows padded to four bytes
+    p16 = rng.integers(0, 1 << 16, (h, w), dtype=np.uint16)
+    stride = ((w * 16 + 31) // 32) * 4
+    rows = b"".join(r.astype("<u2").tobytes().ljust(stride, b"\0") for r in p16[::-1])
+    head = struct.pack("<2sIHHI", b"BM", 14 + 40 + 12 + len(rows), 0, 0, 14 + 40 + 12)
+    dib = struct.pack("<IiiHHIIiiII", 40, w, h, 1, 16, 3, len(rows), 0, 0, 0, 0) + struct.pack("<III", 0xF800, 0x07E0, 0x001F)
+    (tmp_path / "p.bmp").write_bytes(head + dib + rows)
+    got = _texture_via_mtl(tmp_path, "p.bmp")
+    r5, g6, b5 = (p16 >> 11) & 31, (p16 >> 5) & 63, p16 & 31
+    want = np.stack([(r5 << 3) | (r5 >> 2), (g6 << 2) | (g6 >> 4), (b5 << 3) | (b5 >> 2)], -1).astype(np.uint8)
+    assert np.array_equal(got, want)
+
+
+def test_broken_tga_and_bmp_are_refused_and_the_scene_still_loads(tmp_path):
+    import struct
+    (tmp_path / "cut.bmp").write_bytes(b"BM" + b"\0" * 30)
+    (tmp_path / "rle.bmp").write_bytes(struct.pack("<2sIHHI", b"BM", 70, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 2, 2, 1, 8, 1, 0, 0, 0, 0, 0) + b"\0" * 16)
+    (tmp_path / "cut.tga").write_bytes(struct.pack("<BBBHHBHHHHBB", 0, 0, 10, 0, 0, 0, 0, 0, 4, 4, 24, 0) + b"\x83\x01\x02")
+    for name in ("cut.bmp", "rle.bmp", "cut.tga"):
+        (tmp_path / "t.mtl").write_text("newmtl m\nKd 1 1 1\nmap_Kd %s\n" % name)
+        (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl m\nf 1/1 2/2 3/3\n")
+        s = pta.Scene(pta.DEVICE_NONE)
+        assert s.load(str(tmp_path / "t.obj")) and s.num_triangles() == 1  # renders untextured, as after a failed stbi_load
