@@ -49,6 +49,7 @@ struct SceneGpu {
     const float4* nodes;
     const float4* wide;   // BVH kept in memory: per interior node 12 float4 = the node, its left child's node record, its right
                           // child's (zeros where a child is a leaf); nullptr when not built
+    const float4* probe_alias;  // the same address as `nodes` (measurement builds with PT_PROBE_EXTRA_FETCH load through it)
     const int* refs;
     const float4* isect;
     const float4* tri_pos;

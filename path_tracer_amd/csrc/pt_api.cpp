@@ -447,7 +447,7 @@ int flatten_and_upload(PtContext* c) {
 
     SceneGpu& s = c->scene;
     s.wide = nullptr;  // built on demand (ensure_wide_nodes)
-    s.nodes = c->d_nodes.ptr; s.refs = c->d_refs.ptr; s.isect = c->d_isect.ptr;
+    s.nodes = c->d_nodes.ptr; s.probe_alias = c->d_nodes.ptr; s.refs = c->d_refs.ptr; s.isect = c->d_isect.ptr;
     s.tri_pos = c->d_tri_pos.ptr; s.tri_nrm = c->d_tri_nrm.ptr; s.tri_uv = c->d_tri_uv.ptr;
     s.mats = c->d_mats.ptr; s.texels = c->d_texels.ptr; s.env = c->d_env.ptr;
     s.env_w = c->env.w; s.env_h = c->env.h;

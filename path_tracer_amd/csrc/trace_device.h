@@ -287,7 +287,10 @@ __device__ __forceinline__ void node_step_recip(const float4& q0, const float4& 
 // has one more row that is never read: a step stores its deferred child unconditionally, into the
 // row above the top (dead until a push makes it the top) or, from a lane whose LDS rows are full,
 // into that spare row.
-enum { LDS_STACK_ROWS_BVH = 16, LDS_STACK_ROWS_KD = 8 };  // a kd-tree entry is two words (node, entry distance)
+#ifndef PT_BVH_STACK_ROWS
+#define PT_BVH_STACK_ROWS 16   // (a build with another value, for measurements: make EXTRA=-DPT_BVH_STACK_ROWS=8 OUT=...)
+#endif
+enum { LDS_STACK_ROWS_BVH = PT_BVH_STACK_ROWS, LDS_STACK_ROWS_KD = 8 };  // a kd-tree entry is two words (node, entry distance)
 template <bool KD> struct LdsStack { enum { ROWS = KD ? LDS_STACK_ROWS_KD : LDS_STACK_ROWS_BVH, ENTRIES = ROWS - 1 }; };
 // Triangles a lane tests per visit of the leaf phase.
 enum { LEAF_BURST = 4 };
@@ -617,7 +620,41 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 } else {
                     const float4* np = sc.nodes + 4 * (size_t)cur;
                     q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+#ifdef PT_PROBE_EXTRA_FETCH
+                    // measurement build: PT_PROBE_EXTRA_FETCH more loads per step of a node in memory, from the node's
+                    // own 64-byte line through a second pointer (so that they are not merged with the loads above);
+                    // the values are only kept alive, the walk does not change.  PT_PROBE_FETCH_DWORD: 4 bytes a lane
+                    // instead of 16; PT_PROBE_FETCH_ONE_LANE: only the first of the lanes that step loads.
+                    const float4* alias = sc.probe_alias + 4 * (size_t)cur;
+#pragma unroll
+                    for (int k = 0; k < PT_PROBE_EXTRA_FETCH; k++) {
+#ifdef PT_PROBE_FETCH_ONE_LANE
+                        if (lane != __ffsll((long long)lane_mask(true)) - 1) continue;
+#endif
+#ifdef PT_PROBE_FETCH_DWORD
+                        const float x1 = reinterpret_cast<const float*>(alias)[4 * (k & 3)];
+                        asm volatile("" ::"v"(x1));
+#else
+                        const float4 x = alias[k & 3];
+                        asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+#endif
+                    }
+#endif
                 }
+#ifdef PT_PROBE_EXTRA_VALU
+                // measurement build: PT_PROBE_EXTRA_VALU more vector instructions per node step (four independent
+                // chains of fused multiply-adds on values the walk does not use), issued while the node's loads are
+                // in flight
+                {
+                    float c0 = o.x, c1 = o.y, c2 = o.z, c3 = d.x;
+#pragma unroll
+                    for (int k = 0; k < PT_PROBE_EXTRA_VALU / 4; k++) {
+                        c0 = __builtin_fmaf(c0, d.y, inv.x); c1 = __builtin_fmaf(c1, d.z, inv.y);
+                        c2 = __builtin_fmaf(c2, d.x, inv.z); c3 = __builtin_fmaf(c3, d.y, inv.x);
+                    }
+                    asm volatile("" ::"v"(c0), "v"(c1), "v"(c2), "v"(c3));
+                }
+#endif
                 if (COUNT) n_box += 2;
                 NodeStep st;
                 if (FAST) node_step_recip<KD>(q0, q1, q2, q3, o, d, inv, best.t, st);

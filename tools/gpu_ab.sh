@@ -12,7 +12,13 @@ for round in 1 2; do
       i=0
       for flags in "$@"; do
         i=$((i+1))
-        timeout -k 10 150 python bench.py --workload $w --accel $accel --no-cpu-baseline --no-kd --no-sponza --no-pmc ${STEPS:---steps 40 --warmup 5} $flags > $O/ab_tmp.json 2> $O/ab_tmp.err || { tail -5 $O/ab_tmp.err; exit 1; }
+        # a setting of the form "LIB=<file> <flags>" runs the flags on another build of the library (path_tracer_amd/variants/)
+        # "ENV=<NAME=value>[,<NAME=value>...] <flags>" sets environment variables for the run
+        envs=""
+        case "$flags" in ENV=*) envs="${flags%% *}"; envs="${envs#ENV=}"; envs="${envs//,/ }"; flags="${flags#* }";; esac
+        lib=""; f="$flags"
+        case "$flags" in LIB=*) lib="$R/path_tracer_amd/variants/${flags%% *}"; lib="${lib/LIB=/}"; f="${flags#* }"; [ "$f" = "$flags" ] && f="";; esac
+        env $envs PT_AMD_LIB=$lib timeout -k 10 150 python bench.py --workload $w --accel $accel --no-cpu-baseline --no-kd --no-sponza --no-pmc ${STEPS:---steps 40 --warmup 5} $f > $O/ab_tmp.json 2> $O/ab_tmp.err || { tail -5 $O/ab_tmp.err; exit 1; }
         python - "$w" "$accel" "$i" "$flags" $O/ab_tmp.json >> $O/ab_$T.txt <<'PY'
 import json, sys
 w, accel, i, flags, path = sys.argv[1:6]
