@@ -103,7 +103,7 @@ def is_default_workload(args, world):
 
 
 def committed_counters(args, world):
-    """Counter figures of trace_kernel from the committed rocprofv3 --pmc passes (profiles/r02_pmc_*.json:
+    """Counter figures of trace_kernel from the committed rocprofv3 --pmc passes (profiles/r03_pmc_*.json, else r02:
     tools/gpu_pmc_all.sh on the same workload, one frame in flight).  Only attached to the workloads those
     passes ran; None otherwise."""
     tag = None
@@ -117,12 +117,15 @@ def committed_counters(args, world):
         return None
     out = {}
     for kind in ("valu", "cache"):
-        path = os.path.join(ROOT, "profiles", "r02_pmc_%s_%s.json" % (kind, tag))
-        if os.path.exists(path):
-            k = json.load(open(path))["kernels"].get("trace_kernel")
-            if k:
-                out[kind] = k
-                out[kind + "_source"] = "profiles/r02_pmc_%s_%s.json" % (kind, tag)
+        for rnd in ("r03", "r02"):  # the newest passes that were committed
+            name = "profiles/%s_pmc_%s_%s.json" % (rnd, kind, tag)
+            path = os.path.join(ROOT, name)
+            if os.path.exists(path):
+                k = json.load(open(path))["kernels"].get("trace_kernel")
+                if k:
+                    out[kind] = k
+                    out[kind + "_source"] = name
+                    break
     return out or None
 
 

@@ -617,6 +617,14 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                 if (ALL_LDS || cur < staged) {
                     const float4* np = lds_item(lds_nodes, cur);
                     q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
+#ifdef PT_PROBE_EXTRA_LDS
+                    // measurement build: PT_PROBE_EXTRA_LDS more 4-byte LDS reads per step of a staged node
+#pragma unroll
+                    for (int k = 0; k < PT_PROBE_EXTRA_LDS; k++) {
+                        const float x = reinterpret_cast<const volatile float*>(np)[k & 15];
+                        asm volatile("" ::"v"(x));
+                    }
+#endif
                 } else {
                     const float4* np = sc.nodes + 4 * (size_t)cur;
                     q0 = np[0]; q1 = np[1]; q2 = np[2]; q3 = np[3];
@@ -641,6 +649,15 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     }
 #endif
                 }
+#ifdef PT_PROBE_EXTRA_SALU
+                // measurement build: PT_PROBE_EXTRA_SALU more scalar instructions per node step
+                {
+                    unsigned int sx = 0;
+#pragma unroll
+                    for (int k = 0; k < PT_PROBE_EXTRA_SALU; k++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx));
+                    asm volatile("" ::"s"(sx));
+                }
+#endif
 #ifdef PT_PROBE_EXTRA_VALU
                 // measurement build: PT_PROBE_EXTRA_VALU more vector instructions per node step (four independent
                 // chains of fused multiply-adds on values the walk does not use), issued while the node's loads are
