@@ -64,6 +64,7 @@ struct SceneGpu {
     int n_nodes;
     int lds_nodes;  // nodes [0, lds_nodes) are staged in LDS by the trace kernels
     int n_tris;
+    int n_mats;       // materials in `mats`
     int leaf_inline;  // layout of the leaves, see above
     int n_records;    // intersection records in `isect`
     int n_refs;       // entries of `refs` (leaf_inline = 0)

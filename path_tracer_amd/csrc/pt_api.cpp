@@ -455,6 +455,7 @@ int flatten_and_upload(PtContext* c) {
     s.root_ref = root_ref;
     s.n_nodes = (int)order.size();
     s.n_tris = nt;
+    s.n_mats = (int)m.materials.size();
     s.leaf_inline = kd ? 0 : 1;
     s.n_records = (int)(isect.size() / 4);
     s.n_refs = (int)refs.size();

@@ -280,11 +280,48 @@ __device__ __forceinline__ vec3 texel(const SceneGpu& sc, int tw, int th, int of
 //   SHADE_GLASS       Lambertian and glass materials;  SHADE_METAL  Lambertian and metal materials
 //   SHADE_ALL         anything
 enum { SHADE_ALL = 0, SHADE_LAMBERTIAN = 1, SHADE_PLAIN = 2, SHADE_GLASS = 3, SHADE_METAL = 4 };
+// Shading geometry of a small scene staged in LDS.  A hit's three positions, three normals and its material record
+// are otherwise eleven gathered 16-byte loads per path, and it is the rate of such lane-addresses, not bytes, that
+// the shading of a scene this size waits for (cornellbox: shade_kernel 0.125 -> 0.104 ms per launch).  GEO_NONE:
+// nothing staged; GEO_ALL: material records, positions and normals of a scene of at most GEO_LDS_MAX_TRIS
+// triangles and GEO_LDS_MAX_MATS materials.  (Staging only the materials of larger scenes, and the batch's sampler
+// keys, was measured too: nothing gained, the teapot lost 0.6 %.)  Layout (float4 units): MATERIAL_STRIDE records
+// per material, 3 positions per triangle, 3 normals per triangle.
+enum { GEO_NONE = 0, GEO_ALL = 2 };
+enum { GEO_LDS_MAX_TRIS = 256, GEO_LDS_MAX_MATS = 32 };
+struct ShadeLds {
+    const float4* mats;
+    const float4* pos;
+    const float4* nrm;
+};
+__host__ __device__ inline int geometry_kind(const SceneGpu& sc) {
+    return sc.n_mats <= GEO_LDS_MAX_MATS && sc.n_tris <= GEO_LDS_MAX_TRIS ? GEO_ALL : GEO_NONE;
+}
+__host__ __device__ inline size_t geometry_lds_bytes(const SceneGpu& sc) {
+    return geometry_kind(sc) == GEO_ALL ? ((size_t)MATERIAL_STRIDE * sc.n_mats + (size_t)6 * sc.n_tris) * sizeof(float4) : 0;
+}
+// Every thread of the workgroup calls it with the same `kind` (geometry_kind); a barrier must follow before the
+// first shade_region.
+__device__ __forceinline__ ShadeLds stage_geometry(const SceneGpu& sc, float4* geo, int kind) {
+    ShadeLds l;
+    float4* mats = geo;
+    float4* pos = mats + MATERIAL_STRIDE * sc.n_mats;
+    float4* nrm = pos + 3 * sc.n_tris;
+    l.mats = mats; l.pos = pos; l.nrm = nrm;
+    if (kind == GEO_ALL) {
+        const int n_m = MATERIAL_STRIDE * sc.n_mats, n_p = 3 * sc.n_tris;
+        for (int k = threadIdx.x; k < n_m + 2 * n_p; k += blockDim.x)
+            geo[k] = k < n_m ? sc.mats[k] : (k < n_m + n_p ? sc.tri_pos[k - n_m] : sc.tri_nrm[k - n_m - n_p]);
+    }
+    return l;
+}
+
 // CAMERA: the queue holds camera rays, which carry no throughput record (see below).
-template <int KIND, bool CAMERA>
+// GEO: what is read from LDS (stage_geometry) instead of memory.
+template <int KIND, bool CAMERA, int GEO = GEO_NONE>
 __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& b, int level, int max_level, const QueueSet& in,
                                             const float4* __restrict__ hit, const QueueSet& out,
-                                            float4* __restrict__ sample_rad, int n, int* s_out_ptr) {
+                                            float4* __restrict__ sample_rad, int n, int* s_out_ptr, const ShadeLds& lds = ShadeLds()) {
     int& s_out = *s_out_ptr;
     const int blk = blockIdx.x;
     if (threadIdx.x == 0) s_out = 0;
@@ -336,8 +373,10 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
 
                 // hit record: interpolated position, shading normal, texcoords (src/cs488.h:671-675)
                 const float hb = h.z, hg = h.w, ha = 1 - hb - hg;
-                const float4 P0 = sc.tri_pos[3 * tri], P1 = sc.tri_pos[3 * tri + 1], P2 = sc.tri_pos[3 * tri + 2];
-                const float4 N0 = sc.tri_nrm[3 * tri], N1 = sc.tri_nrm[3 * tri + 1], N2 = sc.tri_nrm[3 * tri + 2];
+                const float4* pos = GEO == GEO_ALL ? lds.pos + 3 * tri : sc.tri_pos + 3 * tri;
+                const float4* nrm = GEO == GEO_ALL ? lds.nrm + 3 * tri : sc.tri_nrm + 3 * tri;
+                const float4 P0 = pos[0], P1 = pos[1], P2 = pos[2];
+                const float4 N0 = nrm[0], N1 = nrm[1], N2 = nrm[2];
                 vec3 N = normalize_fast(ha * v3(N0.x, N0.y, N0.z) + hb * v3(N1.x, N1.y, N1.z) + hg * v3(N2.x, N2.y, N2.z));
                 const vec3 P = ha * v3(P0.x, P0.y, P0.z) + hb * v3(P1.x, P1.y, P1.z) + hg * v3(P2.x, P2.y, P2.z);
                 const bool backface = dot(d, N) > 0;  // src/cs488.h:1770-1773
@@ -345,7 +384,7 @@ __device__ __forceinline__ int shade_region(const SceneGpu& sc, const BatchGpu& 
                 const vec3 view = -d;
 
                 const int mid = __float_as_int(P0.w);
-                const float4* mat = sc.mats + MATERIAL_STRIDE * mid;
+                const float4* mat = GEO != GEO_NONE ? lds.mats + MATERIAL_STRIDE * mid : sc.mats + MATERIAL_STRIDE * mid;
                 const float4 m0 = mat[0], m1 = mat[1], m2 = mat[2], m3 = mat[3];
                 const int type = __float_as_int(m0.w);
                 const vec3 Kd = v3(m0.x, m0.y, m0.z), Ks = v3(m1.x, m1.y, m1.z), Ke = v3(m2.x, m2.y, m2.z);

@@ -93,11 +93,12 @@ __global__ void sample_keys_kernel(uint64_t seed, int sample0, int chunk, uint64
 }
 
 // ---- one bounce of shading for every path in the queue ----
-template <int KIND, bool CAMERA>
+template <int KIND, bool CAMERA, int GEO>
 __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int level, int max_level, QueueSet in,
                                                     const float4* __restrict__ hit, QueueSet out,
                                                     float4* __restrict__ sample_rad, const int* __restrict__ qcount_in,
                                                     int* __restrict__ qcount_out) {
+    extern __shared__ float4 geo[];
     __shared__ int s_out;
     const int blk = blockIdx.x;
     int n = qcount_in[blk];
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int
         if (threadIdx.x == 0) qcount_out[blk] = 0;
         return;
     }
-    const int produced = shade_region<KIND, CAMERA>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
+    const ShadeLds lds = stage_geometry(sc, geo, GEO);  // shade_region starts with a barrier
+    const int produced = shade_region<KIND, CAMERA, GEO>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out, lds);
     if (threadIdx.x == 0) qcount_out[blk] = produced;
 }
 
@@ -222,9 +224,16 @@ hipError_t launch_gather_camera_rays(const LaunchCfg& cfg, const CameraGpu& cam,
 hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level, int max_level,
                         QueueSet in, const float4* hit, QueueSet out, float4* sample_rad, const int* qcount_in,
                         int* qcount_out) {
+    const size_t geo_bytes = geometry_lds_bytes(scene);
+    const int geo_kind = geometry_kind(scene);
+#define PT_SHADE_GEO(KIND, CAMERA, GEO)                                                                                     \
+    hipLaunchKernelGGL((shade_kernel<KIND, CAMERA, GEO>), dim3(batch.blocks), dim3(256), geo_bytes, cfg.stream, scene, batch, level, \
+                       max_level, in, hit, out, sample_rad, qcount_in, qcount_out)
 #define PT_SHADE(KIND, CAMERA)                                                                                              \
-    hipLaunchKernelGGL((shade_kernel<KIND, CAMERA>), dim3(batch.blocks), dim3(256), 0, cfg.stream, scene, batch, level, max_level, \
-                       in, hit, out, sample_rad, qcount_in, qcount_out)
+    do {                                                                                                                    \
+        if (geo_kind == GEO_ALL) PT_SHADE_GEO(KIND, CAMERA, GEO_ALL);                                                       \
+        else PT_SHADE_GEO(KIND, CAMERA, GEO_NONE);                                                                          \
+    } while (0)
     const bool camera = in.beta == nullptr;  // camera rays: directions only
     if (scene.shading_kind == SHADE_PLAIN) { if (camera) PT_SHADE(SHADE_PLAIN, true); else PT_SHADE(SHADE_PLAIN, false); }
     else if (scene.shading_kind == SHADE_LAMBERTIAN) { if (camera) PT_SHADE(SHADE_LAMBERTIAN, true); else PT_SHADE(SHADE_LAMBERTIAN, false); }
@@ -232,6 +241,7 @@ hipError_t launch_shade(const LaunchCfg& cfg, const SceneGpu& scene, const Batch
     else if (scene.shading_kind == SHADE_METAL) { if (camera) PT_SHADE(SHADE_METAL, true); else PT_SHADE(SHADE_METAL, false); }
     else { if (camera) PT_SHADE(SHADE_ALL, true); else PT_SHADE(SHADE_ALL, false); }
 #undef PT_SHADE
+#undef PT_SHADE_GEO
     return hipGetLastError();
 }
 

@@ -17,7 +17,7 @@ namespace {
 using namespace trace_dev;
 using namespace shade_dev;
 
-template <bool KD, int SLAB, bool ALL_LDS, int KIND>
+template <bool KD, int SLAB, bool ALL_LDS, int KIND, int GEO>
 __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int level0, int levels, int max_level, QueueSet qa,
                                                    QueueSet qb, float4* __restrict__ hit, float4* __restrict__ sample_rad,
                                                    int* __restrict__ qcount, unsigned long long* __restrict__ block_stats,
@@ -32,7 +32,11 @@ __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int 
     int n = qcount[(size_t)level0 * nb + blk];
     n = n < b.cap_block ? n : b.cap_block;
     const size_t region = (size_t)blk * b.cap_block;
+    // the shading data that is staged (shade_device.h: GEO) sits behind the staged part of the tree
+    float4* const geo = lds_nodes + (dynamic_lds_bytes(sc) + 15) / 16;
     if (n > 0) stage_tree<ALL_LDS>(sc, lds_nodes);  // n is the same for every thread of the workgroup
+    ShadeLds shade_lds = ShadeLds();
+    if (n > 0) shade_lds = stage_geometry(sc, geo, GEO);
     TraceLds<KD> lds;
     lds.nodes = lds_nodes; lds.stat = s_stat; lds.stack = s_stack; lds.stack_t = s_stack_t; lds.count = nullptr;
     const RayPool no_pool = {};
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int 
             const QueueSet& in = (level & 1) ? qb : qa;
             const QueueSet& out = (level & 1) ? qa : qb;
             trace_region<KD, false, SLAB, true, ALL_LDS, false>(sc, in.ray_o, in.ray_d, hit, n, region, block_stats, leave_k, lds, no_pool);
-            n = shade_region<KIND, false>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out);
+            n = shade_region<KIND, false, GEO>(sc, b, level, max_level, in, hit, out, sample_rad, n, &s_out, shade_lds);
             __syncthreads();  // s_out is rewritten by the next level's shading
         }
         if (threadIdx.x == 0) qcount[(size_t)(level + 1) * nb + blk] = n;  // the tally reads every level
@@ -52,10 +56,17 @@ template <bool KD, int SLAB>
 void launch_tail_variant(const LaunchCfg& cfg, const SceneGpu& scene, const BatchGpu& batch, int level0, int levels, int max_level,
                          QueueSet qa, QueueSet qb, float4* hit, float4* sample_rad, int* qcount, unsigned long long* block_stats,
                          int leave_k) {
-    const size_t lds = dynamic_lds_bytes(scene);
+    const size_t lds = ((dynamic_lds_bytes(scene) + 15) / 16) * 16 + geometry_lds_bytes(scene);
+    const int geo_kind = geometry_kind(scene);
 #define PT_TAIL(ALL, KIND)                                                                                             \
-    hipLaunchKernelGGL((tail_kernel<KD, SLAB, ALL, KIND>), dim3(batch.blocks), dim3(256), lds, cfg.stream, scene, batch, \
-                       level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k)
+    do {                                                                                                               \
+        if (geo_kind == GEO_ALL)                                                                                       \
+            hipLaunchKernelGGL((tail_kernel<KD, SLAB, ALL, KIND, GEO_ALL>), dim3(batch.blocks), dim3(256), lds, cfg.stream, scene, batch, \
+                               level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k);      \
+        else                                                                                                           \
+            hipLaunchKernelGGL((tail_kernel<KD, SLAB, ALL, KIND, GEO_NONE>), dim3(batch.blocks), dim3(256), lds, cfg.stream, scene, batch, \
+                               level0, levels, max_level, qa, qb, hit, sample_rad, qcount, block_stats, leave_k);      \
+    } while (0)
 #define PT_TAIL_KIND(ALL)                                                            \
     do {                                                                             \
         if (scene.shading_kind == SHADE_PLAIN) PT_TAIL(ALL, SHADE_PLAIN);            \

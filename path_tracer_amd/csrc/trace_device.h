@@ -316,10 +316,10 @@ __device__ __forceinline__ const float4* lds_item(const float4* base, int i) {
 enum { LDS_RECORDS_MAX = 256, LDS_REFS_MAX = 2048 };
 
 // May the ALL_LDS instantiation serve this scene?  (host side; decides the dynamic LDS size too)
-inline bool fits_lds(const SceneGpu& sc) {
+__host__ __device__ inline bool fits_lds(const SceneGpu& sc) {
     return sc.lds_nodes >= sc.n_nodes && sc.n_records <= LDS_RECORDS_MAX && (sc.leaf_inline || sc.n_refs <= LDS_REFS_MAX);
 }
-inline size_t dynamic_lds_bytes(const SceneGpu& sc) {
+__host__ __device__ inline size_t dynamic_lds_bytes(const SceneGpu& sc) {
     size_t b = (size_t)sc.lds_nodes * (16 * LDS_ITEM_F4);
     if (fits_lds(sc)) b += (size_t)sc.n_records * (16 * LDS_ITEM_F4) + (sc.leaf_inline ? 0 : (size_t)sc.n_refs * 4);
     return b;
