@@ -444,8 +444,13 @@ def launch_ranks(n):
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env))
     code = 0
     live = list(procs)
+    deadline = time.time() + float(os.environ.get("PT_BENCH_LAUNCH_TIMEOUT", "3000"))
     while live:
         time.sleep(0.05)
+        if time.time() > deadline:  # a rank that never returns must not hold the caller for ever
+            for q in live:
+                q.kill()
+            return 124
         for p in list(live):
             rc = p.poll()
             if rc is None:
