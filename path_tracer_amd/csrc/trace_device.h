@@ -445,6 +445,9 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
     int sp = 0, cur = NO_RAY;
     int leaf_k = 0, leaf_n = 0;  // next triangle of the leaf the lane stands on, and the leaf's size
     size_t slot = 0;
+#ifdef PT_KD_MAILBOX
+    unsigned long long tested = 0ull;  // triangles the lane's ray has been tested against
+#endif
     float miss_scale = 1.0f;  // the ray's factor on the environment radiance (ray_o.w), handed on in a miss record
     bool fast_ok = false;
     bool drained = false;  // wave-uniform: the region has no unassigned ray left
@@ -562,6 +565,9 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
         miss_scale = ro.w;
         best.t = FLT_MAX; best.beta = 0.0f; best.gamma = 0.0f; best.tri = -1;
         sp = 0;
+#ifdef PT_KD_MAILBOX
+        tested = 0ull;
+#endif
         if (SLAB == SLAB_RECIP) {
             fast_ok = sc.planes_ok != 0 && recip_ok(o, d, rlo, rhi);
             if (fast_ok) inv = v3(exact_reciprocal(d.x), exact_reciprocal(d.y), exact_reciprocal(d.z));
@@ -770,6 +776,23 @@ __device__ __forceinline__ void trace_region(const SceneGpu& sc, const float4* _
                     const int k = valid ? leaf_k + j : leaf_n - 1;
                     if (COUNT) n_tri += valid ? 1 : 0;
                     if (COUNT) n_wave_rounds += lane == __ffsll((long long)lane_mask(true)) - 1 ? 1 : 0;
+#ifdef PT_KD_MAILBOX
+                    // measurement build: a ray remembers the triangles it has tested (a kd-tree repeats a triangle in
+                    // every leaf it spans; the repeat cannot win, the test accepts only a strictly nearer hit) --
+                    // one bit per triangle, scenes of at most 64 triangles held in LDS.  A round is skipped when no
+                    // lane of the wave has an untested triangle in it.
+                    if (ALL_LDS && sc.n_tris <= 64) {
+                        const int id = lds_refs[off + 1 + k];
+                        const bool test = valid && ((tested >> id) & 1ull) == 0ull;
+                        tested |= test ? (1ull << id) : 0ull;
+                        if (COUNT) n_tri -= valid && !test ? 1 : 0;
+                        if (lane_mask(test) != 0ull) {
+                            const float4* rec = lds_item(lds_records, id);
+                            triangle_round<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, test, best);
+                        }
+                        continue;
+                    }
+#endif
                     const float4* rec = ALL_LDS ? lds_item(lds_records, lds_refs[off + 1 + k])
                                                 : sc.isect + 4 * (size_t)sc.refs[off + 1 + k];
                     triangle_round<SLAB == SLAB_RECIP>(rec[0], rec[1], rec[2], rec[3], o, d, valid, best);
