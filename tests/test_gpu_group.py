@@ -160,7 +160,7 @@ def test_group_completes_overflowed_batches_at_the_next_wait(gpu_device, wait):
 def test_cli_gpus_option_keeps_the_protocol_and_the_image(gpu_device, tmp_path):
     exe = os.path.join(ROOT, "path_tracer_amd", "CS488")
     outs = []
-    for extra in ([], ["--gpus", "1"]):
+    for extra in ([], ["--gpus", "1"], ["--gpus", "1", "--reduce-every", "2"]):  # three frames at two per reduce: the last by the final wait
         pfm = str(tmp_path / ("f%d.pfm" % len(outs)))
         r = subprocess.run([exe, scene_path("cornellbox.obj"), "--accel", "bvh", "--frames", "3", "--spp", "4", "--width", "96", "--height", "72",
                             "--out", pfm, "--stats"] + extra, capture_output=True, text=True, timeout=120)
@@ -174,6 +174,7 @@ def test_cli_gpus_option_keeps_the_protocol_and_the_image(gpu_device, tmp_path):
         raw = open(pfm, "rb").read()
         outs.append(np.frombuffer(raw[-96 * 72 * 12:], np.float32))
     assert np.allclose(outs[0], outs[1], rtol=2e-6, atol=1e-7)
+    assert np.allclose(outs[0], outs[2], rtol=2e-6, atol=1e-7)
 
 
 @pytest.mark.gpu
