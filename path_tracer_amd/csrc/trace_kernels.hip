@@ -1,6 +1,7 @@
 // trace_kernels.hip -- the per-level closest-hit kernel, the ray-batch entry kernels and their
 // launchers (gfx950).  The walk itself is in trace_device.h.
 #include "trace_device.h"
+#include "trace_device_two.h"
 
 #include <mutex>
 
@@ -120,6 +121,35 @@ __global__ __launch_bounds__(256, 5) void trace_kernel_wide(SceneGpu sc, const f
     trace_region<false, false, SLAB_RECIP, true, false, POOL, true>(sc, ray_o, ray_d, hit, n, (size_t)blk * cap_block, block_stats, leave_k, lds, pool);
 }
 
+// Two rays per lane (trace_region_two), for a tree that is walked in memory: every workgroup traces its own region.
+// The stacks have fewer LDS rows per ray than trace_kernel's, so that a CU holds as many workgroups of 512 rays in
+// flight as it holds of trace_kernel's 256.
+template <bool KD>
+__global__ __launch_bounds__(256, 4) void trace_kernel_two(SceneGpu sc, const float4* __restrict__ ray_o,
+                                                        const float4* __restrict__ ray_d, float4* __restrict__ hit,
+                                                        const int* __restrict__ n_ptr, int n_fixed, int cap_block,
+                                                        unsigned long long* __restrict__ block_stats, int leave_k) {
+    __shared__ __attribute__((aligned(16))) unsigned int s_stat[PT_STAT_WORDS];
+    __shared__ __attribute__((aligned(16))) int s_stack[2 * LdsStackTwo<KD>::ROWS * 256];
+    __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? 2 * LdsStackTwo<KD>::ROWS * 256 : 4];
+    const int blk = blockIdx.x;
+    int n = 0;
+    if (n_ptr) {
+        n = n_ptr[blk];
+        n = n < cap_block ? n : cap_block;
+    } else {
+        const long long rest = (long long)n_fixed - (long long)blk * cap_block;
+        n = rest <= 0 ? 0 : (rest < cap_block ? (int)rest : cap_block);
+    }
+    if (n <= 0) return;
+    trace_region_two<KD>(sc, ray_o, ray_d, hit, n, (size_t)blk * cap_block, block_stats, leave_k, s_stat, s_stack, s_stack_t);
+}
+
+// Does `mode` (PT_OPT_TRAVERSAL) ask for two rays per lane and can this launch use that form?
+inline bool two_applies(const SceneGpu& scene, int mode, bool count) {
+    return (mode & 2) != 0 && !count && (mode & 1) != 0 && (mode & 4) == 0 && (mode & 0x8000) == 0 && !fits_lds(scene);
+}
+
 // Does `mode` (PT_OPT_TRAVERSAL) ask for the 192-byte node records and can this launch use them?
 inline bool wide_applies(const SceneGpu& scene, int mode, bool kd, bool count) {
     return (mode & 0x8000) != 0 && !kd && !count && (mode & 1) != 0 && (mode & 4) == 0 && scene.wide != nullptr && !fits_lds(scene);
@@ -175,7 +205,10 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
     const int k = k_bits == 0 ? (fits_lds(scene) ? 4 : 1) : (k_bits == 15 ? 65 : k_bits);  // 65: with at least one lane walking the product exceeds any count of waiting lanes
     const int leave_k = k | (refill << 8);
 #define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats, leave_k
-    if (wide_applies(scene, mode, KD, COUNT)) {
+    if (two_applies(scene, mode, COUNT)) {
+        hipLaunchKernelGGL((trace_kernel_two<KD>), dim3(grid_blocks), dim3(256), 0, cfg.stream, scene, ray_o, ray_d,
+                           hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
+    } else if (wide_applies(scene, mode, KD, COUNT)) {
         const size_t lds = dynamic_lds_bytes(scene);
         if ((mode & 8) != 0 || cap_block > POOL_MAX_REGION)
             hipLaunchKernelGGL((trace_kernel_wide<false>), dim3(grid_blocks), dim3(256), lds, cfg.stream, scene, ray_o, ray_d, hit, n_rays,
@@ -230,6 +263,12 @@ int resident_of(const SceneGpu& scene) {
 // more regions than that the last, partly filled round costs as much as a full one.
 int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode) {
     const bool recip = (mode & 1) != 0;
+    if (two_applies(scene, mode, false)) {
+        int w = 0;
+        const hipError_t e = kd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_two<true>, 256, 0)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_two<false>, 256, 0);
+        if (e == hipSuccess && w >= 1) return w > 8 ? 8 : w;
+    }
     if (wide_applies(scene, mode, kd != 0, false)) {
         int w = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_wide<true>, 256, dynamic_lds_bytes(scene)) == hipSuccess && w >= 1)

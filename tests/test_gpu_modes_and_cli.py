@@ -25,7 +25,7 @@ def test_every_traversal_setting_gives_the_oracle_hits(gpu_device, obj, accel):
     rays = np.concatenate([rays, extra])
     ref = o.trace(rays)
     s = load_gpu_scene(obj, accel)
-    for mode in (0x00, 0x01, 0x04, 0x05, 0x08, 0x09, 0x21, 0x41, 0x49, 0xF1, 0x2041, 0x0841, 0x8001, 0x8009, 0x8841, 0x4040):
+    for mode in (0x00, 0x01, 0x04, 0x05, 0x08, 0x09, 0x21, 0x41, 0x49, 0xF1, 0x2041, 0x0841, 0x8001, 0x8009, 0x8841, 0x03, 0x0b, 0x0843, 0x4040):
         s.set_option(pta.OPT_TRAVERSAL, mode)
         got = s.intersect(rays)
         assert np.array_equal(got["tri"], ref["tri"]), hex(mode)
@@ -43,7 +43,7 @@ def test_pooled_and_private_ray_sources_on_ragged_batches(gpu_device, accel):
     rays = ray_batch(o.get_tris()[0], n_random=600000, n_vertex=600, seed=17)
     ref = o.trace(rays)
     s = load_gpu_scene("teapot.obj", accel)
-    for mode in (0x01, 0x09):
+    for mode in (0x01, 0x09, 0x03):  # 0x03: two rays per lane, private regions
         s.set_option(pta.OPT_TRAVERSAL, mode)
         for n in (1, 63, 64, 65, 255, 257, 4097, 70001, 524288 + 77, len(rays)):
             got = s.intersect(rays[:n])
