@@ -61,6 +61,9 @@ __device__ __forceinline__ void trace_region_two(const SceneGpu& sc, const float
         sp[r] = 0; cur[r] = NO_RAY; leaf_k[r] = 0; leaf_n[r] = 0; slot[r] = 0; miss_scale[r] = 1.0f; fast_ok[r] = false;
     }
     bool drained = false;  // wave-uniform: the region has no unassigned ray left
+    // the node array as a buffer: loads at offsets beyond its size return zeros and make no memory access
+    const __amdgpu_buffer_rsrc_t node_buffer =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(sc.nodes), 0, (int)((unsigned int)sc.n_nodes << 6), 0x00020000);
     const int asked_min = (leave_k_and_refill >> 8) ? (leave_k_and_refill >> 8) : 16;
     const int refill_min = 2 * asked_min;  // the threshold counts idle lanes of a wave with one ray a lane: the same share here
     const int leave_k = leave_k_and_refill & 0xff;
@@ -177,25 +180,24 @@ __device__ __forceinline__ void trace_region_two(const SceneGpu& sc, const float
                 if (walking * leave_k < waiting) break;
                 // Both slots' nodes are requested before either step is taken, always from memory (this form stages no
                 // nodes in LDS: a wave that reads some nodes from LDS and some from memory into the same registers
-                // orders the two, and the second slot's request would wait for the first slot's data).  The two
-                // addresses are formed first and pinned, so that nothing between the eight loads needs a register
-                // that a load in flight still owns.
-                typedef float f4_t __attribute__((ext_vector_type(4)));
-                typedef const __attribute__((address_space(1))) f4_t* node_ptr;
-                unsigned long long a0 = reinterpret_cast<unsigned long long>(sc.nodes + 4 * (size_t)max(cur[0], 0));
-                unsigned long long a1 = reinterpret_cast<unsigned long long>(sc.nodes + 4 * (size_t)max(cur[1], 0));
+                // orders the two, and the second slot's request would wait for the first slot's data).  The loads are
+                // buffer loads that every lane issues for both slots, without a branch (loads under a condition are
+                // moved into the conditional block of the step that uses them, behind the other slot's, and the wait
+                // in front of the first step then has to cover all eight); a slot that is not walking passes an
+                // offset beyond the buffer, for which the hardware returns zeros without touching the cache.  The two
+                // offsets are formed first and pinned, so that nothing between the eight loads needs a register that
+                // a load in flight still owns.
+                typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+                unsigned int a0 = cur[0] >= 0 ? (unsigned int)cur[0] << 6 : 0xfffffff0u;
+                unsigned int a1 = cur[1] >= 0 ? (unsigned int)cur[1] << 6 : 0xfffffff0u;
                 asm volatile("" : "+v"(a0), "+v"(a1));
                 float4 q[2][4];
-                // every lane loads for both slots (a slot that is not walking reads node 0 and drops it): with the
-                // second slot's loads under a condition of their own, the wait before the first step would have to
-                // cover the path on which they were skipped, and so all eight loads
-                auto fetch = [&](auto rc, unsigned long long at) {
+                auto fetch = [&](auto rc, unsigned int at) {
                     constexpr int R = decltype(rc)::value;
-                    node_ptr np = (node_ptr)at;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const f4_t v = np[k];
-                        q[R][k] = make_float4(v.x, v.y, v.z, v.w);
+                        const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(node_buffer, at + 16u * k, 0, 0);
+                        q[R][k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
                     }
                 };
                 auto step = [&](auto rc) {

@@ -5,6 +5,7 @@
 #   -DPT_PROBE_EXTRA_FETCH=n [-DPT_PROBE_FETCH_DWORD] [-DPT_PROBE_FETCH_ONE_LANE]   n more loads per step of a node in memory
 #   -DPT_PROBE_EXTRA_VALU=n / -DPT_PROBE_EXTRA_SALU=n / -DPT_PROBE_EXTRA_LDS=n       n more vector / scalar / LDS-read instructions per node step
 #   -DPT_BVH_STACK_ROWS=n                                                             LDS rows of a BVH lane's traversal stack (default 16)
+#   -DPT_TWO_STACK_ROWS_BVH=n / -DPT_TWO_STACK_ROWS_KD=n                             LDS stack rows per ray of the two-rays-per-lane form (8 / 6)
 # usage: build_variant.sh <name> "<flags>"
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)

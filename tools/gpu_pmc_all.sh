@@ -1,10 +1,11 @@
 #!/bin/bash
 # Every counter pass of one workload, each in a run of its own: kernel trace, two SQ passes, HBM fetch, HBM write,
-# L2 (TCC), L1 (TCP).  usage: gpu_pmc_all.sh <tag> <scene: cornellbox.obj | teapot.obj | sponza> <bvh|kd>
+# L2 (TCC), L1 (TCP).  usage: gpu_pmc_all.sh <tag> <scene: cornellbox.obj | teapot.obj | sponza> <bvh|kd> [traversal mode]
+# (PT_PROF_TAIL_LEVEL in the environment is passed on to the workload)
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=$1; S=${2:-cornellbox.obj}; A=${3:-bvh}
 cd /tmp && export TMPDIR=/tmp
-W="python3 $R/tools/prof_frame.py $S 1024 3 $A"
+W="python3 $R/tools/prof_frame.py $S 1024 3 $A $4"
 pass() {  # name, rocprofv3 arguments...
     local name=$1; shift
     timeout -s KILL 150 rocprofv3 "$@" --output-format csv -d $O/${name}_$T -- $W > $O/${name}_$T.log 2>&1 || { tail -5 $O/${name}_$T.log; exit 1; }

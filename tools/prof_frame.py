@@ -2,6 +2,7 @@
 """Small workload for rocprofv3 passes: a few progressive frames of one scene, no PyTorch.
 One frame in flight at a time unless PT_PROF_STREAMS says otherwise: the passes are read per kernel.  The trace kernel
 is the form that runs with two frames in flight (workgroups on their own regions, traversal bit 3) unless a mode is given.
+PT_PROF_TAIL_LEVEL sets PT_OPT_TAIL_LEVEL (0: one trace launch per bounce level, no fused launch).
 usage: prof_frame.py [scene.obj] [resolution] [frames] [accel bvh|kd] [traversal mode]"""
 import os
 import sys
@@ -32,6 +33,8 @@ else:
 s.pre_calc(accel)
 s.set_option(pta.OPT_STREAMS, int(os.environ.get("PT_PROF_STREAMS", "1")))
 s.set_option(pta.OPT_TRAVERSAL, int(sys.argv[5], 0) if len(sys.argv) > 5 else s.get_option(pta.OPT_TRAVERSAL) | 8)
+if "PT_PROF_TAIL_LEVEL" in os.environ:
+    s.set_option(pta.OPT_TAIL_LEVEL, int(os.environ["PT_PROF_TAIL_LEVEL"]))
 s.set_resolution(*((3840, 2160) if obj == "sponza" else (res, res)))
 for _ in range(frames):
     s.pathtrace(spp)
