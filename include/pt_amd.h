@@ -71,10 +71,10 @@ enum {
                                  the number in use once the tree is built */
     PT_OPT_TRAVERSAL = 8,     /* trace-kernel form; every setting gives bit-identical hits.  bit 0: slab and triangle
                                  quotients from an exact reciprocal plus one exact correction step instead of the
-                                 division sequence (default on); bit 1 (measurement; a tree that is walked in memory, with bit 0
-                                 set and bit 2 clear): every lane walks two rays at a time and requests both rays' nodes before it
-                                 takes either step; every workgroup traces its own region.  Measured 7-17 % slower per launch than
-                                 one ray a lane; off by default; bit 2: refill a wave only when all its lanes are idle
+                                 division sequence (default on); bit 1 (measurement; with bit 0 set and bits 2 and 15 clear): every lane
+                                 walks two rays at a time and requests both rays' nodes before it takes either step; every
+                                 workgroup traces its own region.  Measured 7-19 % slower per launch than one ray a lane on every
+                                 scene; off by default; bit 2: refill a wave only when all its lanes are idle
                                  (measurement); bit 3: every workgroup traces the rays of its own queue region, also where the default
                                  lets the workgroups draw chunks of 64 rays from shared pools (pt_trace_batch, and
                                  rendering with PT_OPT_STREAMS = 1); bits 4..7: k of the node phase's early-leave rule (leave when the lanes

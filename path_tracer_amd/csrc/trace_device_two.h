@@ -7,7 +7,8 @@
 // so a wave has twice the fetches in flight per register file and LDS stack it occupies.  Each ray's own sequence of
 // decisions is trace_region's (trace_device.h; BVH::traverse, src/cs488.h:1671-1706, and the kd-tree's,
 // src/cs488.h:1344-1375), so its hit record is bit-identical; only which lane and which of its two slots walks a
-// ray differs.  Private queue regions, the dynamic refill and the reciprocal slab form only.
+// ray differs.  Private queue regions, the dynamic refill and the reciprocal slab form only.  A scene held entirely in
+// LDS has the same form with the nodes and records read from there (two dependent chains per wave instead of one).
 #pragma once
 
 #include "trace_device.h"
@@ -27,15 +28,18 @@ template <bool KD> struct LdsStackTwo { enum { ROWS = KD ? PT_TWO_STACK_ROWS_KD 
 
 template <int R> using slot_c = std::integral_constant<int, R>;
 
-template <bool KD>
+// ALL_LDS: the whole tree and its leaf records are staged at lds_nodes (stage_tree<true>); otherwise nothing is.
+template <bool KD, bool ALL_LDS>
 __device__ __forceinline__ void trace_region_two(const SceneGpu& sc, const float4* __restrict__ ray_o,
                                                  const float4* __restrict__ ray_d, float4* __restrict__ hit, int n, size_t region,
                                                  unsigned long long* __restrict__ block_stats, int leave_k_and_refill,
-                                                 unsigned int* s_stat, int* s_stack, float* s_stack_t) {
+                                                 const float4* lds_nodes, unsigned int* s_stat, int* s_stack, float* s_stack_t) {
     constexpr int ROWS = LdsStackTwo<KD>::ROWS;
     constexpr int LDS_STACK = LdsStackTwo<KD>::ENTRIES;
     constexpr int DEEP = TRACE_STACK - LDS_STACK;
     const int blk = blockIdx.x;
+    const float4* const lds_records = lds_nodes + LDS_ITEM_F4 * sc.lds_nodes;
+    const int* const lds_refs = reinterpret_cast<const int*>(lds_records + LDS_ITEM_F4 * sc.n_records);
     if (threadIdx.x < 6) s_stat[threadIdx.x] = 0;
     __syncthreads();
 
@@ -178,9 +182,9 @@ __device__ __forceinline__ void trace_region_two(const SceneGpu& sc, const float
                 const int waiting = __popcll(lane_mask((unsigned int)cur[0] > (unsigned int)RAY_DONE)) +
                                     __popcll(lane_mask((unsigned int)cur[1] > (unsigned int)RAY_DONE));
                 if (walking * leave_k < waiting) break;
-                // Both slots' nodes are requested before either step is taken, always from memory (this form stages no
-                // nodes in LDS: a wave that reads some nodes from LDS and some from memory into the same registers
-                // orders the two, and the second slot's request would wait for the first slot's data).  The loads are
+                // Both slots' nodes are requested before either step is taken.  A tree in memory is read from memory
+                // only (no top levels staged in LDS: a wave that reads some nodes from LDS and some from memory into the
+                // same registers orders the two, and the second slot's request would wait for the first slot's data).  The loads are
                 // buffer loads that every lane issues for both slots, without a branch (loads under a condition are
                 // moved into the conditional block of the step that uses them, behind the other slot's, and the wait
                 // in front of the first step then has to cover all eight); a slot that is not walking passes an
@@ -194,6 +198,12 @@ __device__ __forceinline__ void trace_region_two(const SceneGpu& sc, const float
                 float4 q[2][4];
                 auto fetch = [&](auto rc, unsigned int at) {
                     constexpr int R = decltype(rc)::value;
+                    if (ALL_LDS) {  // an idle slot reads node 0 with every other idle lane: one broadcast
+                        const float4* np = lds_item(lds_nodes, max(cur[R], 0));
+                        const float2 kids = *reinterpret_cast<const float2*>(np + 3);
+                        q[R][0] = np[0]; q[R][1] = np[1]; q[R][2] = np[2]; q[R][3] = make_float4(kids.x, kids.y, 0.0f, 0.0f);
+                        return;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const u4_t v = __builtin_amdgcn_raw_buffer_load_b128(node_buffer, at + 16u * k, 0, 0);
@@ -260,14 +270,14 @@ __device__ __forceinline__ void trace_region_two(const SceneGpu& sc, const float
             if ((unsigned int)cur[R] > (unsigned int)RAY_DONE) {
                 const int off = ~cur[R];
                 if (KD && !sc.leaf_inline) {
-                    const int n_here = sc.refs[off];
+                    const int n_here = ALL_LDS ? lds_refs[off] : sc.refs[off];
                     leaf_n[R] = leaf_k[R] == 0 ? n_here : leaf_n[R];
 #pragma unroll
                     for (int j = 0; j < LEAF_BURST; j++) {
                         const bool valid = leaf_k[R] + j < leaf_n[R];
                         if (j > 0 && lane_mask(valid) == 0ull) break;
                         const int k = valid ? leaf_k[R] + j : leaf_n[R] - 1;
-                        const float4* rec = sc.isect + 4 * (size_t)sc.refs[off + 1 + k];
+                        const float4* rec = ALL_LDS ? lds_item(lds_records, lds_refs[off + 1 + k]) : sc.isect + 4 * (size_t)sc.refs[off + 1 + k];
                         triangle_round<true>(rec[0], rec[1], rec[2], rec[3], o[R], d[R], valid, best[R]);
                     }
                 } else {
@@ -276,7 +286,7 @@ __device__ __forceinline__ void trace_region_two(const SceneGpu& sc, const float
                         const bool valid = j == 0 || leaf_k[R] + j < leaf_n[R];
                         if (j > 0 && lane_mask(valid) == 0ull) break;
                         const int k = valid ? leaf_k[R] + j : leaf_n[R] - 1;
-                        const float4* rec = sc.isect + 4 * (size_t)(off + k);
+                        const float4* rec = ALL_LDS ? lds_item(lds_records, off + k) : sc.isect + 4 * (size_t)(off + k);
                         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
                         if (j == 0) leaf_n[R] = leaf_k[R] == 0 ? __float_as_int(r1.w) : leaf_n[R];  // a leaf's first record carries its size
                         triangle_round<true>(r0, r1, r2, r3, o[R], d[R], valid, best[R]);

@@ -121,14 +121,14 @@ __global__ __launch_bounds__(256, 5) void trace_kernel_wide(SceneGpu sc, const f
     trace_region<false, false, SLAB_RECIP, true, false, POOL, true>(sc, ray_o, ray_d, hit, n, (size_t)blk * cap_block, block_stats, leave_k, lds, pool);
 }
 
-// Two rays per lane (trace_region_two), for a tree that is walked in memory: every workgroup traces its own region.
-// The stacks have fewer LDS rows per ray than trace_kernel's, so that a CU holds as many workgroups of 512 rays in
-// flight as it holds of trace_kernel's 256.
-template <bool KD>
+// Two rays per lane (trace_region_two): every workgroup traces its own region.  The stacks have fewer LDS rows per ray
+// than trace_kernel's, so that a CU holds as many workgroups of 512 rays in flight as the registers admit.
+template <bool KD, bool ALL_LDS>
 __global__ __launch_bounds__(256, 4) void trace_kernel_two(SceneGpu sc, const float4* __restrict__ ray_o,
                                                         const float4* __restrict__ ray_d, float4* __restrict__ hit,
                                                         const int* __restrict__ n_ptr, int n_fixed, int cap_block,
                                                         unsigned long long* __restrict__ block_stats, int leave_k) {
+    extern __shared__ float4 lds_nodes[];
     __shared__ __attribute__((aligned(16))) unsigned int s_stat[PT_STAT_WORDS];
     __shared__ __attribute__((aligned(16))) int s_stack[2 * LdsStackTwo<KD>::ROWS * 256];
     __shared__ __attribute__((aligned(16))) float s_stack_t[KD ? 2 * LdsStackTwo<KD>::ROWS * 256 : 4];
@@ -142,12 +142,13 @@ __global__ __launch_bounds__(256, 4) void trace_kernel_two(SceneGpu sc, const fl
         n = rest <= 0 ? 0 : (rest < cap_block ? (int)rest : cap_block);
     }
     if (n <= 0) return;
-    trace_region_two<KD>(sc, ray_o, ray_d, hit, n, (size_t)blk * cap_block, block_stats, leave_k, s_stat, s_stack, s_stack_t);
+    if (ALL_LDS) stage_tree<true>(sc, lds_nodes);
+    trace_region_two<KD, ALL_LDS>(sc, ray_o, ray_d, hit, n, (size_t)blk * cap_block, block_stats, leave_k, lds_nodes, s_stat, s_stack, s_stack_t);
 }
 
 // Does `mode` (PT_OPT_TRAVERSAL) ask for two rays per lane and can this launch use that form?
 inline bool two_applies(const SceneGpu& scene, int mode, bool count) {
-    return (mode & 2) != 0 && !count && (mode & 1) != 0 && (mode & 4) == 0 && (mode & 0x8000) == 0 && !fits_lds(scene);
+    return (mode & 2) != 0 && !count && (mode & 1) != 0 && (mode & 4) == 0 && (mode & 0x8000) == 0;
 }
 
 // Does `mode` (PT_OPT_TRAVERSAL) ask for the 192-byte node records and can this launch use them?
@@ -206,8 +207,12 @@ void launch_by_mode(int mode, const LaunchCfg& cfg, const SceneGpu& scene, const
     const int leave_k = k | (refill << 8);
 #define PT_ARGS cfg, scene, ray_o, ray_d, hit, n_rays, n_fixed, grid_blocks, cap_block, cursors, block_stats, leave_k
     if (two_applies(scene, mode, COUNT)) {
-        hipLaunchKernelGGL((trace_kernel_two<KD>), dim3(grid_blocks), dim3(256), 0, cfg.stream, scene, ray_o, ray_d,
-                           hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
+        if (fits_lds(scene))
+            hipLaunchKernelGGL((trace_kernel_two<KD, true>), dim3(grid_blocks), dim3(256), dynamic_lds_bytes(scene), cfg.stream, scene, ray_o,
+                               ray_d, hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
+        else
+            hipLaunchKernelGGL((trace_kernel_two<KD, false>), dim3(grid_blocks), dim3(256), 0, cfg.stream, scene, ray_o, ray_d,
+                               hit, n_rays, n_fixed, cap_block, block_stats, leave_k);
     } else if (wide_applies(scene, mode, KD, COUNT)) {
         const size_t lds = dynamic_lds_bytes(scene);
         if ((mode & 8) != 0 || cap_block > POOL_MAX_REGION)
@@ -265,8 +270,13 @@ int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode) {
     const bool recip = (mode & 1) != 0;
     if (two_applies(scene, mode, false)) {
         int w = 0;
-        const hipError_t e = kd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_two<true>, 256, 0)
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_two<false>, 256, 0);
+        const bool lds = fits_lds(scene);
+        const size_t bytes = lds ? dynamic_lds_bytes(scene) : 0;
+        const hipError_t e =
+            kd ? (lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_two<true, true>, 256, bytes)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_two<true, false>, 256, bytes))
+               : (lds ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_two<false, true>, 256, bytes)
+                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, trace_kernel_two<false, false>, 256, bytes));
         if (e == hipSuccess && w >= 1) return w > 8 ? 8 : w;
     }
     if (wide_applies(scene, mode, kd != 0, false)) {

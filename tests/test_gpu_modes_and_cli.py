@@ -66,6 +66,22 @@ def test_traversal_settings_give_the_same_image(gpu_device):
         assert np.array_equal(imgs[0], im)  # same hits, same random numbers, no forks in this scene
 
 
+def test_walk_forms_of_a_tree_in_memory_give_the_same_image(gpu_device):
+    """teapot.obj is walked in memory: 64-byte nodes, 192-byte nodes (bit 15) and two rays per lane (bit 1) are the
+    same walk per ray, so a frame's accumulation buffer is the same to the bit."""
+    imgs = []
+    for mode in (0x01, 0x8001, 0x03, 0x2003):
+        s = load_gpu_scene("teapot.obj", pta.BVH)
+        assert not s.get_option(pta.OPT_TREE_IN_LDS)
+        s.set_option(pta.OPT_TRAVERSAL, mode)
+        s.set_resolution(96, 72)
+        s.pathtrace(4)
+        imgs.append(s.accumulation_buffer())
+        s.close()
+    for im in imgs[1:]:
+        assert np.array_equal(imgs[0], im)
+
+
 def test_reciprocal_division_is_exact_on_a_slice(gpu_device):
     """The exhaustive run (all 2^46 significand pairs, no mismatch) is recorded in
     profiles/r01_verify_recip_division.log; here 2^37 pairs from both ends and the middle."""
