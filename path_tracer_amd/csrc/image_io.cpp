@@ -156,52 +156,70 @@ bool load_png_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, 
     }
     if (!have_ihdr || w <= 0 || h <= 0) { err = "PNG without header"; return false; }
     if (w > 32768 || h > 32768) { err = "PNG larger than 32768 pixels a side"; return false; }
-    if (interlace) { err = "interlaced PNG is not supported"; return false; }
+    if (interlace > 1) { err = "unknown PNG interlace method"; return false; }
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels || (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)) { err = "unsupported PNG layout"; return false; }
     const size_t bits_pp = (size_t)channels * depth;
-    const size_t stride = ((size_t)w * bits_pp + 7) / 8;
     const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    // The image as one pass, or as the seven reduced images of Adam7 interlacing: pass p holds the pixels
+    // (x0 + i dx, y0 + j dy), each pass filtered as an image of its own; empty passes have no bytes.
+    struct Pass { int x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const Pass* passes = interlace ? adam7 : &whole;
+    const int n_passes = interlace ? 7 : 1;
+    auto pass_w = [&](const Pass& ps) { return (w - ps.x0 + ps.dx - 1) / ps.dx; };
+    auto pass_h = [&](const Pass& ps) { return (h - ps.y0 + ps.dy - 1) / ps.dy; };
+    size_t raw_size = 0;
+    for (int k = 0; k < n_passes; k++) {
+        const int pw = pass_w(passes[k]), ph = pass_h(passes[k]);
+        if (pw > 0 && ph > 0) raw_size += (((size_t)pw * bits_pp + 7) / 8 + 1) * (size_t)ph;
+    }
+    std::vector<uint8_t> raw(raw_size);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) {
         err = "PNG data does not inflate";
         return false;
     }
-    // undo the scanline filters in place
-    std::vector<uint8_t> prev(stride, 0);
-    for (int y = 0; y < h; y++) {
-        uint8_t* row = raw.data() + (size_t)y * (stride + 1);
-        const int ft = row[0];
-        uint8_t* cur = row + 1;
-        for (size_t i = 0; i < stride; i++) {
-            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-            int add = ft == 0 ? 0 : ft == 1 ? a : ft == 2 ? b : ft == 3 ? (a + b) / 2 : ft == 4 ? paeth(a, b, c) : -1;
-            if (add < 0) { err = "bad PNG filter"; return false; }
-            cur[i] = (uint8_t)(cur[i] + add);
-        }
-        memcpy(prev.data(), cur, stride);
-    }
     rgb.resize((size_t)w * h * 3);
     const int scale = depth == 1 ? 255 : depth == 2 ? 85 : depth == 4 ? 17 : 1;
-    for (int y = 0; y < h; y++) {
-        const uint8_t* cur = raw.data() + (size_t)y * (stride + 1) + 1;
-        uint8_t* dst = rgb.data() + (size_t)y * w * 3;
-        for (int x = 0; x < w; x++) {
-            auto sample = [&](int ch) -> int {  // channel value; 16-bit samples keep their high byte
-                if (depth == 16) return cur[((size_t)x * channels + ch) * 2];
-                if (depth == 8) return cur[(size_t)x * channels + ch];
-                size_t bit = (size_t)x * depth;  // sub-byte depths have one channel
-                return (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
-            };
-            if (ctype == 3) {
-                size_t idx = (size_t)sample(0) * 3;
-                for (int c = 0; c < 3; c++) dst[3 * x + c] = idx + c < palette.size() ? palette[idx + c] : 0;
-            } else if (ctype == 0 || ctype == 4) {
-                uint8_t g = (uint8_t)(depth < 8 ? sample(0) * scale : sample(0));
-                dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = g;
-            } else {
-                for (int c = 0; c < 3; c++) dst[3 * x + c] = (uint8_t)sample(c);
+    size_t at = 0;
+    for (int k = 0; k < n_passes; k++) {
+        const Pass& ps = passes[k];
+        const int pw = pass_w(ps), ph = pass_h(ps);
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t stride = ((size_t)pw * bits_pp + 7) / 8;
+        std::vector<uint8_t> prev(stride, 0);
+        for (int j = 0; j < ph; j++) {
+            uint8_t* row = raw.data() + at;
+            at += stride + 1;
+            const int ft = row[0];
+            uint8_t* cur = row + 1;
+            for (size_t i = 0; i < stride; i++) {  // undo the scanline filter in place
+                int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+                int add = ft == 0 ? 0 : ft == 1 ? a : ft == 2 ? b : ft == 3 ? (a + b) / 2 : ft == 4 ? paeth(a, b, c) : -1;
+                if (add < 0) { err = "bad PNG filter"; return false; }
+                cur[i] = (uint8_t)(cur[i] + add);
+            }
+            memcpy(prev.data(), cur, stride);
+            const int y = ps.y0 + j * ps.dy;
+            for (int i = 0; i < pw; i++) {
+                uint8_t* dst = rgb.data() + ((size_t)y * w + (size_t)(ps.x0 + i * ps.dx)) * 3;
+                auto sample = [&](int ch) -> int {  // channel value; 16-bit samples keep their high byte
+                    if (depth == 16) return cur[((size_t)i * channels + ch) * 2];
+                    if (depth == 8) return cur[(size_t)i * channels + ch];
+                    size_t bit = (size_t)i * depth;  // sub-byte depths have one channel
+                    return (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1 << depth) - 1);
+                };
+                if (ctype == 3) {
+                    size_t idx = (size_t)sample(0) * 3;
+                    for (int c = 0; c < 3; c++) dst[c] = idx + c < palette.size() ? palette[idx + c] : 0;
+                } else if (ctype == 0 || ctype == 4) {
+                    uint8_t g = (uint8_t)(depth < 8 ? sample(0) * scale : sample(0));
+                    dst[0] = dst[1] = dst[2] = g;
+                } else {
+                    for (int c = 0; c < 3; c++) dst[c] = (uint8_t)sample(c);
+                }
             }
         }
     }

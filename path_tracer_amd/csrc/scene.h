@@ -73,7 +73,7 @@ void make_single_triangle(HostMesh& mesh);
 // ---- image_io.cpp ----
 // Radiance RGBE (.hdr), flat or new-style RLE scanlines; output rows flipped to bottom-up.
 bool load_hdr(const char* path, HostImage& img, std::string& err);
-// Non-interlaced PNG of any colour type and bit depth, converted to 8-bit RGB.
+// PNG of any colour type and bit depth, interlaced (Adam7) or not, converted to 8-bit RGB.
 bool load_png_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
 // jpeg_decode.cpp: sequential and progressive Huffman-coded JPEG, 8-bit grey or YCbCr, to 8-bit RGB.
 bool load_jpeg_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);

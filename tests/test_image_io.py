@@ -99,14 +99,72 @@ def test_png_reader_colour_types(tmp_path, mode, bits):
     assert np.array_equal(got, want)
 
 
-def test_interlaced_png_is_refused_and_scene_still_loads(tmp_path, capfd):
-    # hand-made IHDR with the interlace flag set
+def _png_chunk(tag, data):
     import struct
     import zlib
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
 
-    def chunk(tag, data):
-        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
-    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 2, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(b"\0" * 14)) + chunk(b"IEND", b"")
+
+def _adam7_png(samples, depth, ctype, palette=None):
+    """An Adam7-interlaced PNG of `samples` (h x w x channels integers of `depth` bits), written here because
+    Pillow only reads them: seven reduced images, rows packed most significant bit first, filter type 0 or 1."""
+    import struct
+    import zlib
+    h, w, ch = samples.shape
+    raw = bytearray()
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        for j, row in enumerate(sub):
+            vals = row.reshape(-1)
+            if depth == 16:
+                line = b"".join(struct.pack(">H", int(v)) for v in vals)
+            elif depth == 8:
+                line = bytes(int(v) for v in vals)
+            else:
+                bits = "".join(format(int(v), "0%db" % depth) for v in vals)
+                bits += "0" * (-len(bits) % 8)
+                line = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+            bpp = max(ch * depth // 8, 1)
+            if j % 2:  # every other row with the Sub filter
+                line = bytes((line[i] - (line[i - bpp] if i >= bpp else 0)) & 255 for i in range(len(line)))
+                raw += b"\x01" + line
+            else:
+                raw += b"\x00" + line
+    png = b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1))
+    if palette is not None:
+        png += _png_chunk(b"PLTE", bytes(palette))
+    return png + _png_chunk(b"IDAT", zlib.compress(bytes(raw))) + _png_chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 2), (5, 9), (23, 17), (64, 40)])
+@pytest.mark.parametrize("ctype,depth", [(2, 8), (6, 8), (0, 8), (4, 8), (3, 4), (3, 8), (0, 1), (0, 16), (2, 16)])
+def test_interlaced_png(tmp_path, w, h, ctype, depth):
+    """Adam7 files (the reference's stbi_load reads them, src/cs488.h:839-846), including sizes at which some of the
+    seven passes are empty.  The file written here is first read back with Pillow, an independent decoder."""
+    rng = np.random.default_rng(w * 100 + h + depth + ctype)
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    samples = rng.integers(0, 1 << depth, (h, w, ch))
+    palette = rng.integers(0, 256, 3 << depth, dtype=np.uint8) if ctype == 3 else None
+    (tmp_path / "i.png").write_bytes(_adam7_png(samples, depth, ctype, palette))
+    if ctype == 3:
+        want = palette.reshape(-1, 3)[samples[..., 0]]
+    else:
+        v8 = (samples >> 8 if depth == 16 else samples * {1: 255, 2: 85, 4: 17, 8: 1}[depth]).astype(np.uint8)
+        want = np.repeat(v8[..., :1], 3, -1) if ch < 3 else v8[..., :3]
+    if depth <= 8:  # (Pillow keeps 16-bit grey as I;16 and scales it its own way; the 8-bit forms pin the writer above)
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "i.png").convert("RGBA").convert("RGB") if ch in (2, 4)
+                                         else Image.open(tmp_path / "i.png").convert("RGB"), np.uint8), want)
+    got = _texture_via_mtl(tmp_path, "i.png")
+    assert np.array_equal(got, want)
+
+
+def test_png_with_an_unknown_interlace_method_is_refused_and_scene_still_loads(tmp_path, capfd):
+    # hand-made IHDR with interlace method 2, which PNG does not define
+    import struct
+    import zlib
+    png = b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 2, 8, 2, 0, 0, 2)) + _png_chunk(b"IDAT", zlib.compress(b"\0" * 14)) + _png_chunk(b"IEND", b"")
     (tmp_path / "i.png").write_bytes(png)
     (tmp_path / "t.mtl").write_text("newmtl m\nmap_Kd i.png\n")
     (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nusemtl m\nf 1/1 2/1 3/1\n")
