@@ -541,6 +541,8 @@ bool load_texture_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int&
     if (got >= 2 && sig[0] == 0xFF && sig[1] == 0xD8) return load_jpeg_rgb8(path, rgb, w, h, err);
     if (got >= 2 && sig[0] == 'B' && sig[1] == 'M') return load_bmp_rgb8(path, rgb, w, h, err);
     if (got >= 8 && sig[0] == 0x89 && sig[1] == 'P') return load_png_rgb8(path, rgb, w, h, err);
+    if (got >= 6 && sig[0] == 'G' && sig[1] == 'I' && sig[2] == 'F' && sig[3] == '8') return load_gif_rgb8(path, rgb, w, h, err);
+    if (got >= 3 && sig[0] == 'P' && (sig[1] == '5' || sig[1] == '6')) return load_pnm_rgb8(path, rgb, w, h, err);
     // a TGA file has no signature: it is tried last, on a plausible header
     if (looks_like_tga(sig, got)) return load_tga_rgb8(path, rgb, w, h, err);
     return load_png_rgb8(path, rgb, w, h, err);

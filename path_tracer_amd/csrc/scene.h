@@ -82,6 +82,9 @@ bool load_jpeg_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h,
 bool looks_like_tga(const uint8_t* header, size_t n);
 bool load_tga_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
 bool load_bmp_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
+// First image of a GIF on a black canvas; binary PGM / PPM with 8 or 16 bits per sample.
+bool load_gif_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
+bool load_pnm_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);
 // A map_Kd file by its signature: JPEG, PNG, BMP or (no signature: by its header) TGA -- the formats among those the
 // reference's stbi_load reads (src/cs488.h:839-846) that scene files use.
 bool load_texture_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err);

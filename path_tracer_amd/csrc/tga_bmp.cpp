@@ -1,9 +1,9 @@
-// tga_bmp.cpp -- Truevision TGA and Windows BMP textures as 8-bit RGB, rows top-down.
+// tga_bmp.cpp -- Truevision TGA, Windows BMP, GIF (first frame) and binary PNM textures as 8-bit RGB, rows top-down.
 //
-// The reference loads map_Kd files with stbi_load(..., 3) (src/cs488.h:839-846), which also reads these two
+// The reference loads map_Kd files with stbi_load(..., 3) (src/cs488.h:839-846), which also reads these
 // formats; scene files in circulation (the publicly distributed sponza.obj among them) name .tga and .bmp
 // textures.  Alpha, where a file has it, is dropped without compositing, as a three-channel request to that
-// loader does.  Written from the format descriptions; the reference holds no file of either kind, so parity with
+// loader does.  Written from the format descriptions; the reference holds no file of these kinds, so parity with
 // its decoder is pinned only through files written by an independent encoder in the tests.
 #include <cstdio>
 #include <cstring>
@@ -199,6 +199,162 @@ bool load_bmp_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, 
             }
         }
     }
+    return true;
+}
+
+// GIF: the first image of the file on a black canvas of the logical screen's size.  Pixels outside the image's
+// rectangle and pixels of the transparent colour stay black (a decoder that returns the first frame uncomposited
+// leaves them at zero).  Interlaced images are put back in order.
+bool load_gif_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err) {
+    std::vector<uint8_t> buf;
+    if (!slurp(path, buf)) { err = std::string("cannot read ") + path; return false; }
+    if (buf.size() < 13 || memcmp(buf.data(), "GIF8", 4) != 0 || (buf[4] != '7' && buf[4] != '9') || buf[5] != 'a') { err = "not a GIF file"; return false; }
+    w = (int)le16(&buf[6]); h = (int)le16(&buf[8]);
+    if (w <= 0 || h <= 0) { err = "GIF: empty logical screen"; return false; }
+    size_t pos = 13;
+    const uint8_t* global = nullptr;
+    int global_n = 0;
+    if (buf[10] & 0x80) {
+        global_n = 2 << (buf[10] & 7);
+        if (pos + (size_t)global_n * 3 > buf.size()) { err = "GIF: truncated colour table"; return false; }
+        global = &buf[pos];
+        pos += (size_t)global_n * 3;
+    }
+    int transparent = -1;
+    while (pos < buf.size()) {
+        const uint8_t tag = buf[pos++];
+        if (tag == 0x21) {  // extension: label, then sub-blocks; the graphic control extension names the transparent colour
+            if (pos >= buf.size()) break;
+            const uint8_t label = buf[pos++];
+            bool first = true;
+            while (pos < buf.size()) {
+                const size_t n = buf[pos++];
+                if (n == 0) break;
+                if (pos + n > buf.size()) { err = "GIF: truncated extension"; return false; }
+                if (label == 0xF9 && first && n >= 4) transparent = (buf[pos] & 1) ? (int)buf[pos + 3] : -1;
+                first = false;
+                pos += n;
+            }
+        } else if (tag == 0x2C) {
+            if (pos + 9 > buf.size()) { err = "GIF: truncated image descriptor"; return false; }
+            const int ix = (int)le16(&buf[pos]), iy = (int)le16(&buf[pos + 2]), iw = (int)le16(&buf[pos + 4]), ih = (int)le16(&buf[pos + 6]);
+            const uint8_t flags = buf[pos + 8];
+            pos += 9;
+            const uint8_t* table = global;
+            int table_n = global_n;
+            if (flags & 0x80) {
+                table_n = 2 << (flags & 7);
+                if (pos + (size_t)table_n * 3 > buf.size()) { err = "GIF: truncated colour table"; return false; }
+                table = &buf[pos];
+                pos += (size_t)table_n * 3;
+            }
+            if (!table) { err = "GIF: image without a colour table"; return false; }
+            if (ix + iw > w || iy + ih > h) { err = "GIF: image outside the logical screen"; return false; }
+            if (pos >= buf.size()) { err = "GIF: truncated image data"; return false; }
+            const int min_bits = buf[pos++];
+            if (min_bits < 1 || min_bits > 11) { err = "GIF: bad code size"; return false; }
+            std::vector<uint8_t> data;  // the sub-blocks joined
+            while (pos < buf.size()) {
+                const size_t n = buf[pos++];
+                if (n == 0) break;
+                if (pos + n > buf.size()) { err = "GIF: truncated image data"; return false; }
+                data.insert(data.end(), &buf[pos], &buf[pos] + n);
+                pos += n;
+            }
+            // LZW with variable code width (least significant bit first), at most 4096 codes
+            std::vector<uint8_t> idx;
+            idx.reserve((size_t)iw * ih);
+            const int clear = 1 << min_bits, stop = clear + 1;
+            std::vector<int> prefix(4096, -1);
+            std::vector<uint8_t> suffix(4096, 0), first_of(4096, 0), stack;
+            for (int k = 0; k < clear; k++) { suffix[k] = (uint8_t)k; first_of[k] = (uint8_t)k; }
+            int width = min_bits + 1, next = stop + 1, prev = -1;
+            uint32_t acc = 0;
+            int have = 0;
+            size_t at = 0;
+            const size_t total = (size_t)iw * ih;
+            while (idx.size() < total) {
+                while (have < width && at < data.size()) { acc |= (uint32_t)data[at++] << have; have += 8; }
+                if (have < width) break;
+                const int code = (int)(acc & ((1u << width) - 1));
+                acc >>= width; have -= width;
+                if (code == clear) { width = min_bits + 1; next = stop + 1; prev = -1; continue; }
+                if (code == stop) break;
+                int c = code;
+                stack.clear();
+                if (code >= next) {  // the code being defined by this very step: previous string + its own first pixel
+                    if (prev < 0 || code > next) { err = "GIF: corrupt code stream"; return false; }
+                    stack.push_back(first_of[prev]);
+                    c = prev;
+                }
+                while (c >= 0 && stack.size() <= 4096) { stack.push_back(suffix[c]); c = prefix[c]; }
+                const uint8_t head = stack.back();
+                for (size_t k = stack.size(); k-- > 0 && idx.size() < total;) idx.push_back(stack[k]);
+                if (prev >= 0 && next < 4096) {
+                    prefix[next] = prev; suffix[next] = head; first_of[next] = first_of[prev];
+                    next++;
+                    if (next == (1 << width) && width < 12) width++;
+                }
+                prev = code;
+            }
+            rgb.assign((size_t)w * h * 3, 0);
+            // rows of an interlaced image come in four passes: every 8th from 0, every 8th from 4, every 4th from 2, every 2nd from 1
+            std::vector<int> row_of((size_t)ih);
+            if (flags & 0x40) {
+                int r = 0;
+                static const int start[4] = {0, 4, 2, 1}, step[4] = {8, 8, 4, 2};
+                for (int p = 0; p < 4; p++) for (int y = start[p]; y < ih; y += step[p]) row_of[(size_t)r++] = y;
+            } else {
+                for (int y = 0; y < ih; y++) row_of[(size_t)y] = y;
+            }
+            for (size_t k = 0; k < idx.size(); k++) {
+                const int x = ix + (int)(k % (size_t)iw), y = iy + row_of[k / (size_t)iw];
+                const int c = idx[k];
+                if (c == transparent || c >= table_n) continue;
+                uint8_t* dst = &rgb[((size_t)y * w + x) * 3];
+                dst[0] = table[3 * c]; dst[1] = table[3 * c + 1]; dst[2] = table[3 * c + 2];
+            }
+            return true;
+        } else if (tag == 0x3B) {
+            break;
+        } else {
+            err = "GIF: unknown block"; return false;
+        }
+    }
+    err = "GIF: no image";
+    return false;
+}
+
+// Binary PGM (P5) and PPM (P6), 8 or 16 bits per sample (a 16-bit sample keeps its high byte).
+bool load_pnm_rgb8(const char* path, std::vector<uint8_t>& rgb, int& w, int& h, std::string& err) {
+    std::vector<uint8_t> buf;
+    if (!slurp(path, buf)) { err = std::string("cannot read ") + path; return false; }
+    if (buf.size() < 3 || buf[0] != 'P' || (buf[1] != '5' && buf[1] != '6')) { err = "not a binary PGM or PPM file"; return false; }
+    const int channels = buf[1] == '6' ? 3 : 1;
+    size_t pos = 2;
+    auto number = [&](int& out) -> bool {  // white space and # comments, then decimal digits
+        while (pos < buf.size()) {
+            if (buf[pos] == '#') { while (pos < buf.size() && buf[pos] != '\n' && buf[pos] != '\r') pos++; }
+            else if (buf[pos] == ' ' || buf[pos] == '\t' || buf[pos] == '\n' || buf[pos] == '\r' || buf[pos] == '\f' || buf[pos] == '\v') pos++;
+            else break;
+        }
+        if (pos >= buf.size() || buf[pos] < '0' || buf[pos] > '9') return false;
+        long v = 0;
+        while (pos < buf.size() && buf[pos] >= '0' && buf[pos] <= '9' && v < (1L << 24)) v = v * 10 + (buf[pos++] - '0');
+        out = (int)v;
+        return true;
+    };
+    int maxval = 0;
+    if (!number(w) || !number(h) || !number(maxval)) { err = "PNM: bad header"; return false; }
+    if (w <= 0 || h <= 0 || w > (1 << 16) || h > (1 << 16) || maxval <= 0 || maxval > 65535) { err = "PNM: bad dimensions"; return false; }
+    pos++;  // the single white-space byte after the maximum value
+    const int bytes = maxval > 255 ? 2 : 1;
+    const size_t need = (size_t)w * h * channels * bytes;
+    if (pos + need > buf.size()) { err = "PNM: truncated pixel data"; return false; }
+    rgb.resize((size_t)w * h * 3);
+    const uint8_t* src = buf.data() + pos;
+    for (size_t i = 0; i < (size_t)w * h; i++)
+        for (int c = 0; c < 3; c++) rgb[3 * i + c] = src[(i * channels + (channels == 3 ? c : 0)) * bytes];
     return true;
 }
 

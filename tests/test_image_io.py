@@ -256,3 +256,118 @@ def test_broken_tga_and_bmp_are_refused_and_the_scene_still_loads(tmp_path):
         (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl m\nf 1/1 2/2 3/3\n")
         s = pta.Scene(pta.DEVICE_NONE)
         assert s.load(str(tmp_path / "t.obj")) and s.num_triangles() == 1  # renders untextured, as after a failed stbi_load
+
+
+@pytest.mark.parametrize("kind", ["random", "smooth", "two_colours", "interlaced", "offset_frame", "transparent"])
+def test_gif_textures(tmp_path, kind):
+    """First frame of a GIF as a texture (the reference's stbi_load reads them, src/cs488.h:839-846): files written by
+    Pillow -- long and short LZW strings, table overflow and clear codes, interlaced rows --, or assembled here for a
+    frame smaller than the screen and a transparent colour; compared with the palette look-up."""
+    rng = np.random.default_rng(5)
+    w, h = 67, 45
+    pal = rng.integers(0, 256, 768, dtype=np.uint8)
+    if kind == "random":
+        idx = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "smooth":
+        idx = ((np.arange(w)[None, :] // 5 + np.arange(h)[:, None] // 7) % 256).astype(np.uint8)  # long repeated strings
+        w, h = 400, 300
+        idx = np.resize(idx, (h, w))
+    elif kind == "two_colours":
+        idx = rng.integers(0, 2, (h, w), dtype=np.uint8)
+    else:
+        idx = rng.integers(0, 200, (h, w), dtype=np.uint8)
+    img = Image.fromarray(idx, "P")
+    img.putpalette(pal.tolist())
+    path = tmp_path / "g.gif"
+    want = pal.reshape(256, 3)[idx]
+    if kind == "interlaced":
+        img.save(path, interlace=1)
+    elif kind in ("offset_frame", "transparent"):
+        # re-pack Pillow's image block into a file with a larger screen / a graphic control extension
+        import struct
+        img.save(path, interlace=0)
+        raw = path.read_bytes()
+        at = raw.index(b"\x2c", 13 + 768)   # the image descriptor follows the global colour table (and extensions)
+        while raw[at + 1:at + 9] != struct.pack("<HHHH", 0, 0, w, h):
+            at = raw.index(b"\x2c", at + 1)
+        block = raw[at + 10:]
+        if kind == "offset_frame":
+            W, H, ox, oy = w + 9, h + 6, 4, 3
+            head = b"GIF89a" + struct.pack("<HHBBB", W, H, 0xF7, 0, 0) + bytes(pal)
+            path.write_bytes(head + b"\x2c" + struct.pack("<HHHHB", ox, oy, w, h, 0) + block)
+            full = np.zeros((H, W, 3), np.uint8)
+            full[oy:oy + h, ox:ox + w] = want
+            want = full
+        else:
+            head = b"GIF89a" + struct.pack("<HHBBB", w, h, 0xF7, 0, 0) + bytes(pal)
+            gce = b"\x21\xf9\x04" + struct.pack("<BHB", 1, 0, 17) + b"\x00"   # colour 17 is transparent
+            path.write_bytes(head + gce + b"\x2c" + struct.pack("<HHHHB", 0, 0, w, h, 0) + block)
+            want = want.copy()
+            want[idx == 17] = 0
+    else:
+        img.save(path)
+    if kind not in ("offset_frame", "transparent"):
+        assert np.array_equal(np.asarray(Image.open(path).convert("RGB"), np.uint8), want)  # Pillow wrote what we think
+    got = _texture_via_mtl(tmp_path, "g.gif")
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("mode", ["RGB", "L", "I;16"])
+def test_pnm_textures(tmp_path, mode):
+    rng = np.random.default_rng(6)
+    w, h = 31, 22
+    if mode == "I;16":
+        arr = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+        (tmp_path / "p.pgm").write_bytes(b"P5\n# a comment\n%d %d\n65535\n" % (w, h) + arr.astype(">u2").tobytes())
+        want = np.repeat((arr >> 8).astype(np.uint8)[..., None], 3, -1)
+        name = "p.pgm"
+    else:
+        arr = rng.integers(0, 256, (h, w, 3) if mode == "RGB" else (h, w), dtype=np.uint8)
+        name = "p.ppm" if mode == "RGB" else "p.pgm"
+        Image.fromarray(arr, mode).save(tmp_path / name)
+        want = arr if mode == "RGB" else np.repeat(arr[..., None], 3, -1)
+    got = _texture_via_mtl(tmp_path, name)
+    assert np.array_equal(got, want)
+
+
+def test_corrupt_texture_files_are_refused_or_decoded_never_fatal(tmp_path):
+    """Truncated and bit-flipped files of every texture format: the scene still loads (the reference prints "Unable to
+    load texture" and goes on, src/cs488.h:843-845).  (The same mutations, 7 800 files, ran clean through the decoders
+    built with AddressSanitizer and UBSan on the host.)"""
+    rng = np.random.default_rng(9)
+    w, h = 24, 18
+    idx = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    pimg = Image.fromarray(idx, "P")
+    pimg.putpalette(rng.integers(0, 256, 768, dtype=np.uint8).tolist())
+    cimg = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB")
+    seeds = tmp_path / "seeds"
+    seeds.mkdir()
+    pimg.save(seeds / "a.gif")
+    pimg.save(seeds / "b.gif", interlace=1)
+    cimg.save(seeds / "c.ppm")
+    cimg.save(seeds / "d.tga")
+    cimg.save(seeds / "e.tga", compression="tga_rle")
+    cimg.save(seeds / "f.bmp")
+    pimg.save(seeds / "g.bmp")
+    cimg.save(seeds / "h.jpg")
+    cimg.save(seeds / "i.jpg", progressive=True)
+    cimg.save(seeds / "j.png")
+    (seeds / "k.png").write_bytes(_adam7_png(rng.integers(0, 256, (h, w, 3)), 8, 2))
+    (tmp_path / "t.obj").write_text("mtllib t.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl m\nf 1/1 2/2 3/3\n")
+    for seed in sorted(seeds.iterdir()):
+        raw = seed.read_bytes()
+        for k in range(40):
+            b = bytearray(raw)
+            if k % 3 == 0:
+                b = b[:rng.integers(1, len(b))]
+            elif k % 3 == 1:
+                for _ in range(rng.integers(1, 6)):
+                    b[rng.integers(0, len(b))] = rng.integers(0, 256)
+            else:
+                b[rng.integers(0, min(len(b), 64))] = rng.integers(0, 256)
+            name = "m" + seed.suffix
+            (tmp_path / name).write_bytes(bytes(b))
+            (tmp_path / "t.mtl").write_text("newmtl m\nKd 1 1 1\nmap_Kd %s\n" % name)
+            s = pta.Scene(pta.DEVICE_NONE)
+            assert s.load(str(tmp_path / "t.obj"))
+            s.close()
