@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256, 4) void trace_kernel_two(SceneGpu sc, const fl
 
 // Does `mode` (PT_OPT_TRAVERSAL) ask for two rays per lane and can this launch use that form?
 inline bool two_applies(const SceneGpu& scene, int mode, bool count) {
-    return (mode & 2) != 0 && !count && (mode & 1) != 0 && (mode & 4) == 0 && (mode & 0x8000) == 0;
+    // (its node loads address the node array through a 32-bit byte offset)
+    return (mode & 2) != 0 && !count && (mode & 1) != 0 && (mode & 4) == 0 && (mode & 0x8000) == 0 && scene.n_nodes < (1 << 25);
 }
 
 // Does `mode` (PT_OPT_TRAVERSAL) ask for the 192-byte node records and can this launch use them?
