@@ -875,14 +875,17 @@ int use_device(PtContext* c) {
 }
 
 // Batches in flight, unless the caller chose: three -- except for frames of more than 4 Mi samples of a scene whose
-// tree is walked in LDS and whose paths do not fork, where the third brings nothing (cornellbox at 1024 x 1024 x 10:
-// +0.3 %, its kd-tree -1 %; at the reference's 512 x 384 x 10: +15 %; teapot +14 %, cornellbox-alpha +5 %, a
-// 210 k-triangle courtyard +4 %) and costs a lane's queues.
+// tree is walked in LDS and whose shading is the plain kind (diffuse surfaces and lights only: the Cornell box), where
+// the third brings a frame 0-2 % (its kd-tree -0.6 %) and costs a lane's queues.  Third lane against two at
+// 1024 x 1024 x 10: cornellbox-glass +6 %, cornellbox-metal +4 % (kd-tree +8 %), cornellbox-alpha and
+// cornellball-glass +-0.5 %; at the reference's 512 x 384 x 10: cornellbox +15 %; teapot +14 %, a 210 k-triangle
+// courtyard +4 %.  (A context whose frames go into a collective keeps two, see ensure_lanes' callers.)
 int choose_lanes(PtContext* c, size_t frame_samples) {
     if (!c->lanes_auto || c->ext_accum || c->group || c->lanes_for_frame == frame_samples) return PT_OK;
     c->lanes_for_frame = frame_samples;
     const SceneGpu& s = c->scene;
-    const int lanes = (s.lds_nodes >= s.n_nodes && !s.fixed_radiance && frame_samples > ((size_t)4 << 20)) ? 2 : 3;
+    const bool plain = s.shading_kind == 2;  // SHADE_PLAIN
+    const int lanes = (s.lds_nodes >= s.n_nodes && plain && !s.fixed_radiance && frame_samples > ((size_t)4 << 20)) ? 2 : 3;
     if (lanes != c->n_lanes) {
         if (c->device != PT_DEVICE_NONE) PT_HIP(c, hipStreamSynchronize(c->stream));  // every lane is idle after this
         c->n_lanes = lanes;

@@ -1,5 +1,6 @@
-// trace_device_two.h -- measurement form of the closest-hit walk for trees that are walked in memory:
-// every lane carries TWO rays (gfx950).
+// trace_device_two.h -- measurement form of the closest-hit walk: every lane carries TWO rays (gfx950).
+// Written for trees that are walked in memory; slower than one ray a lane on every scene measured, and kept behind a
+// setting for that measurement.
 //
 // The walk of a large tree waits for its node fetches.  One way to have more of them in flight per SIMD is more
 // resident waves; this form is the other one: a lane holds the state of two independent rays, and a step of the

@@ -397,10 +397,10 @@ def test_frames_in_flight_do_not_change_the_image(gpu_device, obj, accel):
 @pytest.mark.gpu
 def test_batches_in_flight_are_chosen_per_scene(gpu_device):
     """Unless the caller sets PT_OPT_STREAMS it is chosen when a frame is queued: two batches in flight for large
-    frames of a scene walked in LDS without translucent surfaces, three otherwise; a context whose frames go into a
+    frames of a scene walked in LDS whose surfaces are all diffuse, three otherwise; a context whose frames go into a
     collective (an external per-frame buffer) keeps two; a value the caller set is left alone."""
     for obj, w, h, want in (("cornellbox.obj", 1024, 1024, 2), ("cornellbox.obj", 512, 384, 3), ("cornellbox-alpha.obj", 1024, 1024, 3),
-                            ("teapot.obj", 1024, 1024, 3)):
+                            ("cornellbox-glass.obj", 1024, 1024, 3), ("teapot.obj", 1024, 1024, 3)):
         s = load_gpu_scene(obj, pta.BVH)
         s.set_resolution(w, h)
         s.pathtrace(10)
