@@ -741,7 +741,10 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     const bool small_batch = c->frame_samples <= ((size_t)4 << 20) && c->frame_samples > 0;
     // (a tree in memory: 4, and 2 for a small batch as well -- teapot 512 x 384: 5.8 -> 7.5 Grays/s, its kd-tree 2.8 -> 3.8; at 1024 x 1024
     // 11.0 -> 11.7; the 210 k-triangle courtyard +1.4 %; the deep levels of an open scene are nearly empty launches otherwise)
-    int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : (small_batch ? 2 : 6)) : (small_batch ? 2 : 4)) : c->tail_level;
+    // (a small batch of a kd-tree in LDS, or of any tree in LDS under the heavier shading kinds, already after the camera rays: at 512 x 384 x 10
+    // cornellbox kd-tree 8.87 -> 9.16 Grays/s, cornellbox-glass 11.99 -> 12.48, its kd-tree 7.85 -> 8.20; the cornellbox BVH loses 1.3 % there)
+    const bool early = in_lds && (c->accel == PT_ACCEL_KD || !light_shading);
+    int tail = c->tail_level == 255 ? (in_lds ? (c->accel == PT_ACCEL_KD && light_shading && !own_stream ? 1 : (small_batch ? (early ? 1 : 2) : 6)) : (small_batch ? 2 : 4)) : c->tail_level;
     // ... and, once the rays per level of an earlier batch of this size have come back (no wait: the copy is looked at when
     // its event has passed), from those: the fused launch takes over at the first level that holds fewer than 2.4 M rays
     // (level 1: fewer than 0.6 M), at level 6 at the latest (4 for a tree in memory).  Measured optima this reproduces: cornellbox 1024 x 1024 6
@@ -754,7 +757,7 @@ int run_batch(PtContext* c, const CameraGpu& cam, int pixel0, int n_pixels, int 
     if (c->tail_level == 255 && c->level_rays_slots == b.n_slots && !(in_lds && c->accel == PT_ACCEL_KD && light_shading && !own_stream)) {
         tail = in_lds ? 6 : 4;  // the latest: where a tree of that kind is handed over with every level well filled
         for (int level = 1; level < tail && level < (int)c->level_rays.size(); level++)
-            if (c->level_rays[level] < (level == 1 ? 600000ull : 2400000ull)) { tail = level; break; }
+            if (c->level_rays[level] < (level == 1 && !early ? 600000ull : 2400000ull)) { tail = level; break; }
     }
     const bool fuse = tail > 0 && tail < levels && !c->count_tests && (c->traversal & 4) == 0;
     const int split = fuse ? tail : levels;
