@@ -17,8 +17,16 @@ namespace {
 using namespace trace_dev;
 using namespace shade_dev;
 
+// Six workgroups per CU (80 vector registers): left to itself the compiler takes 83-113, four or five waves per SIMD.
+// Against that, same call, alternating: small frames (512 x 384 x 10, where the fused launch takes over after the first
+// levels) cornellbox +1 %, cornellbox-glass +4 % (kd-tree +2 %), teapot +1 % (kd-tree +5 %); at 1024 x 1024 bunny and
+// teapot kd-trees +4 %, testObj +2 %, the courtyard's kd-tree +2 %, its BVH -0.6 %, cornellbox +-0.3 %.  Eight (64
+// registers) spills in the heavier shading kinds: cornellbox-glass -6 %.  (make EXTRA=-DPT_TAIL_MIN_BLOCKS=n for another.)
+#ifndef PT_TAIL_MIN_BLOCKS
+#define PT_TAIL_MIN_BLOCKS 6
+#endif
 template <bool KD, int SLAB, bool ALL_LDS, int KIND, int GEO>
-__global__ __launch_bounds__(256) void tail_kernel(SceneGpu sc, BatchGpu b, int level0, int levels, int max_level, QueueSet qa,
+__global__ __launch_bounds__(256, PT_TAIL_MIN_BLOCKS) void tail_kernel(SceneGpu sc, BatchGpu b, int level0, int levels, int max_level, QueueSet qa,
                                                    QueueSet qb, float4* __restrict__ hit, float4* __restrict__ sample_rad,
                                                    int* __restrict__ qcount, unsigned long long* __restrict__ block_stats,
                                                    int leave_k) {
