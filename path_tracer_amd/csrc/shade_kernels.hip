@@ -93,8 +93,11 @@ __global__ void sample_keys_kernel(uint64_t seed, int sample0, int chunk, uint64
 }
 
 // ---- one bounce of shading for every path in the queue ----
+#ifndef PT_SHADE_MIN_BLOCKS
+#define PT_SHADE_MIN_BLOCKS 1   // (a build that holds shade_kernel to fewer registers, for measurements: make EXTRA=-DPT_SHADE_MIN_BLOCKS=6)
+#endif
 template <int KIND, bool CAMERA, int GEO>
-__global__ __launch_bounds__(256) void shade_kernel(SceneGpu sc, BatchGpu b, int level, int max_level, QueueSet in,
+__global__ __launch_bounds__(256, PT_SHADE_MIN_BLOCKS) void shade_kernel(SceneGpu sc, BatchGpu b, int level, int max_level, QueueSet in,
                                                     const float4* __restrict__ hit, QueueSet out,
                                                     float4* __restrict__ sample_rad, const int* __restrict__ qcount_in,
                                                     int* __restrict__ qcount_out) {
