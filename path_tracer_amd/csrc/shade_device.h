@@ -35,6 +35,7 @@
 #include "device_math.h"
 #include "device_types.h"
 #include "pt_math.h"
+#include "trace_device.h"  // what the fused kernel stages of the tree, for the LDS budget below
 
 namespace pt {
 
@@ -294,8 +295,15 @@ struct ShadeLds {
     const float4* pos;
     const float4* nrm;
 };
+// The fused kernel stages the geometry behind its part of the tree and beside its stacks, of which the stacks and
+// counters take less than GEO_LDS_STATIC; a gfx950 workgroup can have 160 KiB of LDS.  (With the staged part of the
+// tree chosen per scene the sum stays below 50 KiB; PT_OPT_LDS_NODES can ask for a stage that the trace kernel can just
+// launch with, and the fused kernel then leaves the geometry in memory.)
+enum { GEO_LDS_STATIC = 17 * 1024, GEO_LDS_WORKGROUP = 160 * 1024 };
 __host__ __device__ inline int geometry_kind(const SceneGpu& sc) {
-    return sc.n_mats <= GEO_LDS_MAX_MATS && sc.n_tris <= GEO_LDS_MAX_TRIS ? GEO_ALL : GEO_NONE;
+    if (sc.n_mats > GEO_LDS_MAX_MATS || sc.n_tris > GEO_LDS_MAX_TRIS) return GEO_NONE;
+    const size_t geo = ((size_t)MATERIAL_STRIDE * sc.n_mats + (size_t)6 * sc.n_tris) * sizeof(float4);
+    return GEO_LDS_STATIC + trace_dev::dynamic_lds_bytes(sc) + 16 + geo <= GEO_LDS_WORKGROUP ? GEO_ALL : GEO_NONE;
 }
 __host__ __device__ inline size_t geometry_lds_bytes(const SceneGpu& sc) {
     return geometry_kind(sc) == GEO_ALL ? ((size_t)MATERIAL_STRIDE * sc.n_mats + (size_t)6 * sc.n_tris) * sizeof(float4) : 0;
