@@ -291,8 +291,8 @@ int trace_resident_blocks_per_cu(const SceneGpu& scene, int kd, int mode) {
 }
 
 bool trace_kernel_fits(const SceneGpu& scene, int kd, int mode) {
-    // static LDS of the kernel (stacks, counters) + the dynamic stage must stay within the 64 KiB a workgroup gets
-    // without an opt-in; the occupancy query says 0 (or fails) beyond it
+    // static LDS of the kernel (stacks, counters) + the dynamic stage must stay within what a workgroup can have
+    // (160 KiB on gfx950); the occupancy query says 0 (or fails) beyond it
     const bool recip = (mode & 1) != 0;
     const int n = kd ? (recip ? resident_of<true, SLAB_RECIP>(scene) : resident_of<true, SLAB_DIVIDE>(scene))
                      : (recip ? resident_of<false, SLAB_RECIP>(scene) : resident_of<false, SLAB_DIVIDE>(scene));
