@@ -290,7 +290,10 @@ __device__ __forceinline__ void node_step_recip(const float4& q0, const float4& 
 #ifndef PT_BVH_STACK_ROWS
 #define PT_BVH_STACK_ROWS 16   // (a build with another value, for measurements: make EXTRA=-DPT_BVH_STACK_ROWS=8 OUT=...)
 #endif
-enum { LDS_STACK_ROWS_BVH = PT_BVH_STACK_ROWS, LDS_STACK_ROWS_KD = 8 };  // a kd-tree entry is two words (node, entry distance)
+#ifndef PT_KD_STACK_ROWS
+#define PT_KD_STACK_ROWS 8
+#endif
+enum { LDS_STACK_ROWS_BVH = PT_BVH_STACK_ROWS, LDS_STACK_ROWS_KD = PT_KD_STACK_ROWS };  // a kd-tree entry is two words (node, entry distance)
 template <bool KD> struct LdsStack { enum { ROWS = KD ? LDS_STACK_ROWS_KD : LDS_STACK_ROWS_BVH, ENTRIES = ROWS - 1 }; };
 // Triangles a lane tests per visit of the leaf phase.
 enum { LEAF_BURST = 4 };

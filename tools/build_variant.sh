@@ -4,7 +4,7 @@
 # PT_AMD_LIB).  The measurement flags are described where they are used in csrc/trace_device.h:
 #   -DPT_PROBE_EXTRA_FETCH=n [-DPT_PROBE_FETCH_DWORD] [-DPT_PROBE_FETCH_ONE_LANE]   n more loads per step of a node in memory
 #   -DPT_PROBE_EXTRA_VALU=n / -DPT_PROBE_EXTRA_SALU=n / -DPT_PROBE_EXTRA_LDS=n       n more vector / scalar / LDS-read instructions per node step
-#   -DPT_BVH_STACK_ROWS=n                                                             LDS rows of a BVH lane's traversal stack (default 16)
+#   -DPT_BVH_STACK_ROWS=n / -DPT_KD_STACK_ROWS=n                                      LDS rows of a lane's traversal stack (defaults 16 / 8; on the Cornell boxes 12 / 6 and 10 / 5 change nothing)
 #   -DPT_TWO_STACK_ROWS_BVH=n / -DPT_TWO_STACK_ROWS_KD=n                             LDS stack rows per ray of the two-rays-per-lane form (8 / 6)
 # usage: build_variant.sh <name> "<flags>"
 set -e
